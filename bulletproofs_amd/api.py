@@ -1,0 +1,325 @@
+"""Host-side Python mirror of the reference's hot-path functions on top of the
+C ABI.  Names follow the reference: msm_unchecked (ark-ec, called from
+src/msm.rs:84-87), inner_product / sum (src/vector_ops.rs:159-179),
+fold_scalars / fold_generators (src/ipa/mod.rs:215-234), normalize_batch,
+batch_inversion, HPoly::coeffs (s_vector).
+
+Values are numpy arrays in the arkworks memory form: a field vector is (n,4)
+uint64 Montgomery limbs; a point vector is a tuple (x (n,4), y (n,4), inf (n,)
+uint8); a group result is 12 uint64 (Jacobian X,Y,Z, normalised).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+
+SECP256K1, VESTA = 0, 1
+VEC_ADD, VEC_SUB, VEC_HADAMARD, VEC_SCALE, VEC_AXPY = 0, 1, 2, 3, 4
+IPA_BULLETPROOF, IPA_POLYCOMMIT = 0, 1
+
+
+class BpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{_lib.ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def _f(a):
+    """field vector -> contiguous (n,4) uint64"""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, 4)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+def _pts(P):
+    x, y, inf = P
+    x, y = _f(x), _f(y)
+    if x.shape != y.shape:
+        raise ValueError("x/y planes differ in length")
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8).reshape(-1)
+        if inf.shape[0] != x.shape[0]:
+            raise ValueError("infinity plane length mismatch")
+    return x, y, inf
+
+
+class Context:
+    """One GPU + one stream (bp_ctx)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        rc = lib.bp_init(device, C.byref(h))
+        if rc != 0:
+            raise BpError(rc, "bp_init failed (no usable gfx950 device?)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.bp_shutdown(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise BpError(rc, lib.bp_last_error(self.h).decode())
+
+    def set_msm_window(self, c: int):
+        self._chk(lib.bp_set_msm_window(self.h, c))
+
+    def sync(self):
+        self._chk(lib.bp_sync(self.h))
+
+    # ---- MSM ------------------------------------------------------------
+    def msm_unchecked(self, curve, bases, scalars):
+        x, y, inf = _pts(bases)
+        s = _f(scalars)
+        n = min(x.shape[0], s.shape[0])  # msm_unchecked zips to the shorter length
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(lib.bp_msm(self.h, curve, _p(x), _p(y), _p(inf), _p(s), n, _p(out)))
+        return out
+
+    def msm_dev(self, curve, d_x, d_y, d_inf, d_s, n):
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(lib.bp_msm_dev(self.h, curve, d_x, d_y, d_inf, d_s, n, _p(out)))
+        return out
+
+    def msm2_dev(self, curve, part0, part1):
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(lib.bp_msm2_dev(self.h, curve, *part0, *part1, _p(out)))
+        return out
+
+    def register_bases(self, curve, bases):
+        return Bases(self, curve, bases)
+
+    def msm_windows_dev(self, curve, d_x, d_y, d_inf, d_s, n, d_windows):
+        nw, cb = C.c_int(), C.c_int()
+        self._chk(lib.bp_msm_windows_dev(self.h, curve, d_x, d_y, d_inf, d_s, n, d_windows, C.byref(nw), C.byref(cb)))
+        return nw.value, cb.value
+
+    def msm_combine_windows_dev(self, curve, d_windows, n_parts, n_windows, window_bits):
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(lib.bp_msm_combine_windows_dev(self.h, curve, d_windows, n_parts, n_windows, window_bits, _p(out)))
+        return out
+
+    # ---- field vectors ----------------------------------------------------
+    def inner_product(self, curve, a, b):
+        a, b = _f(a), _f(b)
+        n = min(a.shape[0], b.shape[0])
+        out = np.zeros(4, dtype=np.uint64)
+        self._chk(lib.bp_inner_product(self.h, curve, _p(a), _p(b), n, _p(out)))
+        return out
+
+    def sum(self, curve, a):
+        a = _f(a)
+        out = np.zeros(4, dtype=np.uint64)
+        self._chk(lib.bp_sum(self.h, curve, _p(a), a.shape[0], _p(out)))
+        return out
+
+    def fold_scalars(self, curve, left, right, x, y):
+        l, r = _f(left), _f(right)
+        h = min(l.shape[0], r.shape[0])
+        x, y = _f(x), _f(y)
+        out = np.zeros((h, 4), dtype=np.uint64)
+        self._chk(lib.bp_fold_scalars(self.h, curve, _p(l), _p(r), h, _p(x), _p(y), _p(out)))
+        return out
+
+    def vec_op(self, curve, op, a, b=None, s=None):
+        a = _f(a)
+        n = a.shape[0]
+        if b is not None:
+            b = _f(b)
+            n = min(n, b.shape[0])
+        if s is not None:
+            s = _f(s)
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self._chk(lib.bp_vec_op(self.h, curve, op, _p(a), _p(b), _p(s), n, _p(out)))
+        return out
+
+    def vector_add(self, curve, a, b):
+        return self.vec_op(curve, VEC_ADD, a, b)
+
+    def vector_sub(self, curve, a, b):
+        return self.vec_op(curve, VEC_SUB, a, b)
+
+    def hadamard(self, curve, a, b):
+        return self.vec_op(curve, VEC_HADAMARD, a, b)
+
+    def scale(self, curve, a, s):
+        return self.vec_op(curve, VEC_SCALE, a, None, s)
+
+    def axpy(self, curve, a, s, b):
+        return self.vec_op(curve, VEC_AXPY, a, b, s)
+
+    def s_vector(self, curve, challenges, challenge_inverses):
+        ch, chi = _f(challenges), _f(challenge_inverses)
+        k = ch.shape[0]
+        if chi.shape[0] != k:
+            raise ValueError("challenge / inverse count mismatch")
+        out = np.zeros((1 << k, 4), dtype=np.uint64)
+        self._chk(lib.bp_s_vector(self.h, curve, _p(ch), _p(chi), k, _p(out)))
+        return out
+
+    def powers(self, curve, x, n):
+        x = _f(x)
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self._chk(lib.bp_powers(self.h, curve, _p(x), n, _p(out)))
+        return out
+
+    def batch_inversion(self, curve, v, field=0):
+        v = _f(v).copy()
+        self._chk(lib.bp_batch_inverse(self.h, curve, field, _p(v), v.shape[0]))
+        return v
+
+    # ---- curve vectors ------------------------------------------------------
+    def fold_generators(self, curve, left, right, x, y):
+        lx, ly, li = _pts(left)
+        rx, ry, ri = _pts(right)
+        h = min(lx.shape[0], rx.shape[0])
+        x, y = _f(x), _f(y)
+        ox = np.zeros((h, 4), dtype=np.uint64)
+        oy = np.zeros((h, 4), dtype=np.uint64)
+        oi = np.zeros(h, dtype=np.uint8)
+        self._chk(
+            lib.bp_fold_generators(self.h, curve, _p(lx), _p(ly), _p(li), _p(rx), _p(ry), _p(ri), h, _p(x), _p(y),
+                                   _p(ox), _p(oy), _p(oi)))
+        return ox, oy, oi
+
+    def scale_points(self, curve, points, scalars):
+        px, py, pi = _pts(points)
+        s = _f(scalars)
+        n = min(px.shape[0], s.shape[0])
+        ox = np.zeros((n, 4), dtype=np.uint64)
+        oy = np.zeros((n, 4), dtype=np.uint64)
+        oi = np.zeros(n, dtype=np.uint8)
+        self._chk(lib.bp_scale_points(self.h, curve, _p(px), _p(py), _p(pi), _p(s), n, _p(ox), _p(oy), _p(oi)))
+        return ox, oy, oi
+
+    def normalize_batch(self, curve, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.uint64).reshape(-1, 12)
+        n = xyz.shape[0]
+        ox = np.zeros((n, 4), dtype=np.uint64)
+        oy = np.zeros((n, 4), dtype=np.uint64)
+        oi = np.zeros(n, dtype=np.uint8)
+        self._chk(lib.bp_normalize_batch(self.h, curve, _p(xyz), n, _p(ox), _p(oy), _p(oi)))
+        return ox, oy, oi
+
+    # ---- measurement ----------------------------------------------------------
+    def int_mad_peak(self, iters=2000):
+        v = C.c_double()
+        self._chk(lib.bp_bench_int_mad_peak(self.h, iters, C.byref(v)))
+        return v.value
+
+    def last_kernel_ms(self, group):
+        v = C.c_float()
+        self._chk(lib.bp_last_kernel_ms(self.h, group, C.byref(v)))
+        return v.value
+
+    def ipa_begin(self, curve, variant, gs, hs, a, b):
+        return IpaSession(self, curve, variant, gs, hs, a, b)
+
+
+class Bases:
+    """Device-resident base points (bp_bases): the CRS uploaded once."""
+
+    def __init__(self, ctx: Context, curve, bases):
+        x, y, inf = _pts(bases)
+        h = C.c_void_p()
+        ctx._chk(lib.bp_bases_register(ctx.h, curve, _p(x), _p(y), _p(inf), x.shape[0], C.byref(h)))
+        self.ctx, self.h, self.curve = ctx, h, curve
+
+    def __len__(self):
+        return lib.bp_bases_len(self.h)
+
+    def msm(self, scalars, offset=0, n=None):
+        s = _f(scalars)
+        if n is None:
+            n = s.shape[0]
+        out = np.zeros(12, dtype=np.uint64)
+        self.ctx._chk(lib.bp_msm_resident(self.ctx.h, self.h, offset, n, _p(s), _p(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib.bp_bases_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass
+
+
+class IpaSession:
+    """Device-resident G, H, a, b across the rounds of ipa::prove
+    (src/ipa/mod.rs:33-95) or poly_commit::prove (src/poly_commit/mod.rs:69-105)."""
+
+    def __init__(self, ctx: Context, curve, variant, gs, hs, a, b):
+        gx, gy, gi = _pts(gs)
+        a, b = _f(a), _f(b)
+        n = a.shape[0]
+        if hs is not None:
+            hx, hy, hi = _pts(hs)
+        else:
+            hx = hy = hi = None
+        h = C.c_void_p()
+        ctx._chk(
+            lib.bp_ipa_begin(ctx.h, curve, variant, _p(gx), _p(gy), _p(gi), _p(hx), _p(hy), _p(hi), _p(a), _p(b), n,
+                             C.byref(h)))
+        self.ctx, self.h, self.has_h = ctx, h, hs is not None
+
+    def __len__(self):
+        return lib.bp_ipa_len(self.h)
+
+    def round_lr(self):
+        L = np.zeros(12, dtype=np.uint64)
+        R = np.zeros(12, dtype=np.uint64)
+        cl = np.zeros(4, dtype=np.uint64)
+        cr = np.zeros(4, dtype=np.uint64)
+        self.ctx._chk(lib.bp_ipa_round_lr(self.h, _p(L), _p(R), _p(cl), _p(cr)))
+        return L, R, cl, cr
+
+    def round_fold(self, x, x_inv):
+        x, xi = _f(x), _f(x_inv)
+        self.ctx._chk(lib.bp_ipa_round_fold(self.h, _p(x), _p(xi)))
+
+    def read(self):
+        n = len(self)
+        gx = np.zeros((n, 4), dtype=np.uint64)
+        gy = np.zeros((n, 4), dtype=np.uint64)
+        gi = np.zeros(n, dtype=np.uint8)
+        a = np.zeros((n, 4), dtype=np.uint64)
+        b = np.zeros((n, 4), dtype=np.uint64)
+        if self.has_h:
+            hx = np.zeros((n, 4), dtype=np.uint64)
+            hy = np.zeros((n, 4), dtype=np.uint64)
+            hi = np.zeros(n, dtype=np.uint8)
+        else:
+            hx = hy = hi = None
+        self.ctx._chk(lib.bp_ipa_read(self.h, _p(gx), _p(gy), _p(gi), _p(hx), _p(hy), _p(hi), _p(a), _p(b)))
+        return (gx, gy, gi), (None if hx is None else (hx, hy, hi)), a, b
+
+    def free(self):
+        if self.h:
+            lib.bp_ipa_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass

@@ -1,0 +1,846 @@
+// C ABI of libbp_gpu (see include/bp_gpu.h): contexts, workspace, host<->device
+// staging, and the IPA round session.  No CPU fallback exists: without a usable
+// HIP device bp_init fails.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "bp_host_math.h"
+#include "bp_internal.h"
+
+using namespace bp;
+
+namespace {
+
+enum Slot {
+  S_IN0, S_IN1, S_IN2, S_IN3, S_IN4, S_IN5, S_IN6,
+  S_OUT0, S_OUT1, S_OUT2,
+  S_KEYS_A, S_KEYS_B, S_VALS_A, S_VALS_B, S_SORT_TMP, S_BSTART, S_BEND, S_BUCKETS, S_SEGS,
+  S_WINDOWS, S_TABLE, S_SMALL, S_COUNT
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct bp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::string err;
+  DevBuf buf[S_COUNT];
+  void* pinned = nullptr;
+  size_t pinned_cap = 0;
+  hipEvent_t ev[6] = {};
+  int c_override = 0;
+  float last_ms[3] = {0, 0, 0};
+};
+
+struct bp_bases {
+  bp_ctx* ctx;
+  int curve;
+  size_t n;
+  u32* x;
+  u32* y;
+  uint8_t* inf;
+};
+
+struct bp_ipa {
+  bp_ctx* ctx;
+  int curve;
+  int variant;
+  size_t n;
+  u32 *gx, *gy, *hx, *hy, *a, *b;
+  uint8_t *ginf, *hinf;
+};
+
+namespace {
+
+int fail(bp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
+  if (ctx) {
+    char tmp[512];
+    if (e != hipSuccess)
+      snprintf(tmp, sizeof tmp, "%s: %s", what, hipGetErrorString(e));
+    else
+      snprintf(tmp, sizeof tmp, "%s", what);
+    ctx->err = tmp;
+  }
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                     \
+  do {                                                        \
+    hipError_t _e = (call);                                   \
+    if (_e != hipSuccess) {                                   \
+      int _c = (_e == hipErrorOutOfMemory) ? BP_E_OOM : BP_E_HIP; \
+      return fail(ctx, _c, #call, _e);                        \
+    }                                                         \
+  } while (0)
+
+#define CHK(call)              \
+  do {                         \
+    int _r = (call);           \
+    if (_r != BP_OK) return _r; \
+  } while (0)
+
+struct Guard {
+  std::unique_lock<std::mutex> lk;
+  explicit Guard(bp_ctx* c) : lk(c->mu) { (void)hipSetDevice(c->device); }
+};
+
+int reserve(bp_ctx* ctx, int slot, size_t bytes, void** out) {
+  DevBuf& b = ctx->buf[slot];
+  if (bytes < 256) bytes = 256;
+  if (b.cap < bytes) {
+    if (b.p) {
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, hipFree(b.p));
+      b.p = nullptr;
+      b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    want = (want + 4095) & ~(size_t)4095;
+    HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+  }
+  *out = b.p;
+  return BP_OK;
+}
+
+int reserve_pinned(bp_ctx* ctx, size_t bytes) {
+  if (ctx->pinned_cap >= bytes) return BP_OK;
+  if (ctx->pinned) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr;
+    ctx->pinned_cap = 0;
+  }
+  size_t want = (bytes + 65535) & ~(size_t)65535;
+  HIPCHK(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+  ctx->pinned_cap = want;
+  return BP_OK;
+}
+
+bool curve_ok(int curve) { return curve == BP_SECP256K1 || curve == BP_VESTA; }
+
+int upload(bp_ctx* ctx, int slot, const void* host, size_t bytes, void** dev) {
+  CHK(reserve(ctx, slot, bytes, dev));
+  if (bytes) HIPCHK(ctx, hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return BP_OK;
+}
+
+FeArg to_arg(const uint64_t v[4]) {
+  FeArg a;
+  memcpy(a.v, v, 32);
+  return a;
+}
+
+FeArg to_canonical_fr(int curve, const uint64_t v[4]) {
+  host::HFe m;
+  memcpy(m.v, v, 32);
+  host::HFe c = curve == BP_SECP256K1 ? host::h_from_mont<Secp256k1Fr>(m) : host::h_from_mont<VestaFr>(m);
+  FeArg a;
+  memcpy(a.v, c.v, 32);
+  return a;
+}
+
+void finish_windows(int curve, const uint64_t* win, int n_windows, int c, uint64_t out_xyz[12]) {
+  if (curve == BP_SECP256K1) {
+    auto r = host::hx_combine_windows<Secp256k1Fq>(win, n_windows, c);
+    host::hx_to_xyz<Secp256k1Fq>(r, out_xyz);
+  } else {
+    auto r = host::hx_combine_windows<VestaFq>(win, n_windows, c);
+    host::hx_to_xyz<VestaFq>(r, out_xyz);
+  }
+}
+
+// device phase of an MSM: leaves plan->n_windows XYZZ window sums in S_WINDOWS
+int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, MsmPlan* plan,
+               u32** d_windows) {
+  size_t n = p0.n + p1.n;
+  hipError_t e = msm_make_plan(n, ctx->c_override, plan);
+  if (e != hipSuccess) return fail(ctx, BP_E_ARG, "msm plan (n too large?)", e);
+  MsmWorkspace ws{};
+  void* p;
+  CHK(reserve(ctx, S_KEYS_A, plan->keys_bytes, &p)); ws.keys_a = (u32*)p;
+  CHK(reserve(ctx, S_KEYS_B, plan->keys_bytes, &p)); ws.keys_b = (u32*)p;
+  CHK(reserve(ctx, S_VALS_A, plan->keys_bytes, &p)); ws.vals_a = (u32*)p;
+  CHK(reserve(ctx, S_VALS_B, plan->keys_bytes, &p)); ws.vals_b = (u32*)p;
+  CHK(reserve(ctx, S_SORT_TMP, plan->sort_tmp_bytes, &p)); ws.sort_tmp = p;
+  CHK(reserve(ctx, S_BSTART, plan->bounds_bytes, &p)); ws.bucket_start = (u32*)p;
+  CHK(reserve(ctx, S_BEND, plan->bounds_bytes, &p)); ws.bucket_end = (u32*)p;
+  CHK(reserve(ctx, S_BUCKETS, plan->bucket_bytes, &p)); ws.buckets = (u32*)p;
+  CHK(reserve(ctx, S_SEGS, plan->seg_bytes, &p)); ws.segs = (u32*)p;
+  CHK(reserve(ctx, S_WINDOWS, plan->win_bytes, &p)); ws.windows = (u32*)p;
+  HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  e = msm_run(curve, p0, p1, *plan, ws, ctx->stream, ctx->ev[2], ctx->ev[3]);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "msm_run", e);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  *d_windows = ws.windows;
+  return BP_OK;
+}
+
+void msm_collect_times(bp_ctx* ctx, bool had_points) {
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_ms[1] = ms;
+  if (had_points && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[0] = ms;
+}
+
+int msm_full(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, uint64_t out_xyz[12]) {
+  MsmPlan plan;
+  u32* d_win = nullptr;
+  CHK(msm_device(ctx, curve, p0, p1, &plan, &d_win));
+  CHK(reserve_pinned(ctx, plan.win_bytes));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  msm_collect_times(ctx, plan.n_total != 0);
+  finish_windows(curve, (const uint64_t*)ctx->pinned, plan.n_windows, plan.c, out_xyz);
+  return BP_OK;
+}
+
+int dot_dev(bp_ctx* ctx, int curve, const u32* a, const u32* b, size_t n, uint64_t out[4]) {
+  void* part;
+  CHK(reserve(ctx, S_SMALL, (size_t)(kDotBlocks + 1) * 32, &part));
+  u32* partials = (u32*)part;
+  u32* d_out = partials + (size_t)kDotBlocks * 8;
+  HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  hipError_t e = launch_inner_product(curve, a, b, n, partials, d_out, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "inner_product", e);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+  CHK(reserve_pinned(ctx, 32));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out, ctx->pinned, 32);
+  float ms;
+  if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->last_ms[2] = ms;
+  return BP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bp_init(int device, bp_ctx** out) {
+  if (!out) return BP_E_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return BP_E_HIP;
+  if (device < 0 || device >= count) return BP_E_ARG;
+  if (hipSetDevice(device) != hipSuccess) return BP_E_HIP;
+  bp_ctx* c = new (std::nothrow) bp_ctx();
+  if (!c) return BP_E_OOM;
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return BP_E_HIP;
+  }
+  for (auto& e : c->ev) {
+    if (hipEventCreate(&e) != hipSuccess) {
+      bp_shutdown(c);
+      return BP_E_HIP;
+    }
+  }
+  *out = c;
+  return BP_OK;
+}
+
+void bp_shutdown(bp_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& b : ctx->buf)
+    if (b.p) (void)hipFree(b.p);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (auto& e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* bp_last_error(bp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int bp_sync(bp_ctx* ctx) {
+  if (!ctx) return BP_E_ARG;
+  Guard g(ctx);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_set_msm_window(bp_ctx* ctx, int c) {
+  if (!ctx || c < 0 || c == 1 || c > 20) return BP_E_ARG;
+  Guard g(ctx);
+  ctx->c_override = c;
+  return BP_OK;
+}
+
+// ---- MSM ---------------------------------------------------------------------
+
+int bp_msm_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64_t* d_y, const uint8_t* d_inf,
+               const uint64_t* d_scalars, size_t n, uint64_t out_xyz[12]) {
+  if (!ctx || !out_xyz || (n && (!d_x || !d_y || !d_scalars))) return fail(ctx, BP_E_ARG, "bp_msm_dev: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  MsmPart p0{(const u32*)d_x, (const u32*)d_y, d_inf, (const u32*)d_scalars, n};
+  MsmPart p1{nullptr, nullptr, nullptr, nullptr, 0};
+  return msm_full(ctx, curve, p0, p1, out_xyz);
+}
+
+int bp_msm2_dev(bp_ctx* ctx, int curve, const uint64_t* d_x0, const uint64_t* d_y0, const uint8_t* d_inf0,
+                const uint64_t* d_s0, size_t n0, const uint64_t* d_x1, const uint64_t* d_y1,
+                const uint8_t* d_inf1, const uint64_t* d_s1, size_t n1, uint64_t out_xyz[12]) {
+  if (!ctx || !out_xyz || (n0 && (!d_x0 || !d_y0 || !d_s0)) || (n1 && (!d_x1 || !d_y1 || !d_s1)))
+    return fail(ctx, BP_E_ARG, "bp_msm2_dev: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  MsmPart p0{(const u32*)d_x0, (const u32*)d_y0, d_inf0, (const u32*)d_s0, n0};
+  MsmPart p1{(const u32*)d_x1, (const u32*)d_y1, d_inf1, (const u32*)d_s1, n1};
+  return msm_full(ctx, curve, p0, p1, out_xyz);
+}
+
+int bp_msm(bp_ctx* ctx, int curve, const uint64_t* bases_x, const uint64_t* bases_y, const uint8_t* bases_inf,
+           const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
+  if (!ctx || !out_xyz || (n && (!bases_x || !bases_y || !scalars))) return fail(ctx, BP_E_ARG, "bp_msm: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  void *dx, *dy, *di = nullptr, *ds;
+  CHK(upload(ctx, S_IN0, bases_x, n * 32, &dx));
+  CHK(upload(ctx, S_IN1, bases_y, n * 32, &dy));
+  if (bases_inf) CHK(upload(ctx, S_IN2, bases_inf, n, &di));
+  CHK(upload(ctx, S_IN3, scalars, n * 32, &ds));
+  MsmPart p0{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)ds, n};
+  MsmPart p1{nullptr, nullptr, nullptr, nullptr, 0};
+  return msm_full(ctx, curve, p0, p1, out_xyz);
+}
+
+int bp_bases_register(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, const uint8_t* inf, size_t n,
+                      bp_bases** out) {
+  if (!ctx || !out || (n && (!x || !y))) return fail(ctx, BP_E_ARG, "bp_bases_register: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  bp_bases* b = new (std::nothrow) bp_bases();
+  if (!b) return fail(ctx, BP_E_OOM, "host allocation");
+  b->ctx = ctx;
+  b->curve = curve;
+  b->n = n;
+  b->x = b->y = nullptr;
+  b->inf = nullptr;
+  size_t bytes = n ? n * 32 : 32;
+  hipError_t e;
+  if ((e = hipMalloc((void**)&b->x, bytes)) != hipSuccess || (e = hipMalloc((void**)&b->y, bytes)) != hipSuccess ||
+      (e = hipMalloc((void**)&b->inf, n ? n : 1)) != hipSuccess) {
+    if (b->x) (void)hipFree(b->x);
+    if (b->y) (void)hipFree(b->y);
+    delete b;
+    return fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "bp_bases_register: hipMalloc", e);
+  }
+  if (n) {
+    HIPCHK(ctx, hipMemcpyAsync(b->x, x, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->y, y, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (inf)
+      HIPCHK(ctx, hipMemcpyAsync(b->inf, inf, n, hipMemcpyHostToDevice, ctx->stream));
+    else
+      HIPCHK(ctx, hipMemsetAsync(b->inf, 0, n, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  *out = b;
+  return BP_OK;
+}
+
+void bp_bases_free(bp_bases* b) {
+  if (!b) return;
+  Guard g(b->ctx);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  (void)hipFree(b->x);
+  (void)hipFree(b->y);
+  (void)hipFree(b->inf);
+  delete b;
+}
+
+size_t bp_bases_len(const bp_bases* b) { return b ? b->n : 0; }
+
+int bp_msm_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n, const uint64_t* scalars,
+                    uint64_t out_xyz[12]) {
+  if (!ctx || !bases || !out_xyz || (n && !scalars)) return fail(ctx, BP_E_ARG, "bp_msm_resident: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_msm_resident: bases belong to another context");
+  if (offset > bases->n || n > bases->n - offset) return fail(ctx, BP_E_ARG, "bp_msm_resident: range outside bases");
+  Guard g(ctx);
+  void* ds;
+  CHK(upload(ctx, S_IN3, scalars, n * 32, &ds));
+  MsmPart p0{bases->x + offset * 8, bases->y + offset * 8, bases->inf + offset, (const u32*)ds, n};
+  MsmPart p1{nullptr, nullptr, nullptr, nullptr, 0};
+  return msm_full(ctx, bases->curve, p0, p1, out_xyz);
+}
+
+int bp_msm_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64_t* d_y, const uint8_t* d_inf,
+                       const uint64_t* d_scalars, size_t n, uint64_t* d_windows, int* n_windows,
+                       int* window_bits) {
+  if (!ctx || !d_windows || !n_windows || !window_bits || (n && (!d_x || !d_y || !d_scalars)))
+    return fail(ctx, BP_E_ARG, "bp_msm_windows_dev: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  MsmPart p0{(const u32*)d_x, (const u32*)d_y, d_inf, (const u32*)d_scalars, n};
+  MsmPart p1{nullptr, nullptr, nullptr, nullptr, 0};
+  MsmPlan plan;
+  u32* d_win = nullptr;
+  CHK(msm_device(ctx, curve, p0, p1, &plan, &d_win));
+  if (plan.n_windows > 64) return fail(ctx, BP_E_ARG, "bp_msm_windows_dev: more than 64 windows; raise the window width");
+  HIPCHK(ctx, hipMemcpyAsync(d_windows, d_win, plan.win_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  msm_collect_times(ctx, n != 0);
+  *n_windows = plan.n_windows;
+  *window_bits = plan.c;
+  return BP_OK;
+}
+
+int bp_msm_combine_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_windows, int n_parts, int n_windows,
+                               int window_bits, uint64_t out_xyz[12]) {
+  if (!ctx || !d_windows || !out_xyz || n_parts < 1 || n_windows < 1 || n_windows > 4096 || window_bits < 1)
+    return fail(ctx, BP_E_ARG, "bp_msm_combine_windows_dev: bad argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  void* d_out;
+  size_t bytes = (size_t)n_windows * 128;
+  CHK(reserve(ctx, S_WINDOWS, bytes, &d_out));
+  hipError_t e = launch_window_combine(curve, (const u32*)d_windows, n_parts, n_windows, (u32*)d_out, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "window_combine", e);
+  CHK(reserve_pinned(ctx, bytes));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  finish_windows(curve, (const uint64_t*)ctx->pinned, n_windows, window_bits, out_xyz);
+  return BP_OK;
+}
+
+// ---- field-vector kernels ------------------------------------------------------
+
+int bp_inner_product_dev(bp_ctx* ctx, int curve, const uint64_t* d_a, const uint64_t* d_b, size_t n,
+                         uint64_t out[4]) {
+  if (!ctx || !out || (n && (!d_a || !d_b))) return fail(ctx, BP_E_ARG, "bp_inner_product_dev: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) {
+    memset(out, 0, 32);
+    return BP_OK;
+  }
+  return dot_dev(ctx, curve, (const u32*)d_a, (const u32*)d_b, n, out);
+}
+
+int bp_inner_product(bp_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]) {
+  if (!ctx || !out || (n && (!a || !b))) return fail(ctx, BP_E_ARG, "bp_inner_product: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) {
+    memset(out, 0, 32);
+    return BP_OK;
+  }
+  void *da, *db;
+  CHK(upload(ctx, S_IN0, a, n * 32, &da));
+  CHK(upload(ctx, S_IN1, b, n * 32, &db));
+  return dot_dev(ctx, curve, (const u32*)da, (const u32*)db, n, out);
+}
+
+int bp_sum(bp_ctx* ctx, int curve, const uint64_t* a, size_t n, uint64_t out[4]) {
+  if (!ctx || !out || (n && !a)) return fail(ctx, BP_E_ARG, "bp_sum: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) {
+    memset(out, 0, 32);
+    return BP_OK;
+  }
+  void* da;
+  CHK(upload(ctx, S_IN0, a, n * 32, &da));
+  return dot_dev(ctx, curve, (const u32*)da, nullptr, n, out);
+}
+
+int bp_fold_scalars_dev(bp_ctx* ctx, int curve, const uint64_t* d_l, const uint64_t* d_r, size_t h,
+                        const uint64_t x[4], const uint64_t y[4], uint64_t* d_out) {
+  if (!ctx || !x || !y || (h && (!d_l || !d_r || !d_out))) return fail(ctx, BP_E_ARG, "bp_fold_scalars_dev: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  hipError_t e = launch_fold_scalars(curve, (const u32*)d_l, (const u32*)d_r, h, to_arg(x), to_arg(y), (u32*)d_out,
+                                     ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_scalars", e);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  float ms;
+  if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->last_ms[2] = ms;
+  return BP_OK;
+}
+
+int bp_fold_scalars(bp_ctx* ctx, int curve, const uint64_t* l, const uint64_t* r, size_t h, const uint64_t x[4],
+                    const uint64_t y[4], uint64_t* out) {
+  if (!ctx || !x || !y || (h && (!l || !r || !out))) return fail(ctx, BP_E_ARG, "bp_fold_scalars: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (h == 0) return BP_OK;
+  void *dl, *dr, *dout;
+  CHK(upload(ctx, S_IN0, l, h * 32, &dl));
+  CHK(upload(ctx, S_IN1, r, h * 32, &dr));
+  CHK(reserve(ctx, S_OUT0, h * 32, &dout));
+  hipError_t e = launch_fold_scalars(curve, (const u32*)dl, (const u32*)dr, h, to_arg(x), to_arg(y), (u32*)dout,
+                                     ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_scalars", e);
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, h * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_vec_op(bp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b, const uint64_t s[4], size_t n,
+              uint64_t* out) {
+  if (!ctx || op < BP_VEC_ADD || op > BP_VEC_AXPY) return fail(ctx, BP_E_ARG, "bp_vec_op: bad op");
+  bool need_b = op != BP_VEC_SCALE, need_s = (op == BP_VEC_SCALE || op == BP_VEC_AXPY);
+  if ((n && (!a || !out || (need_b && !b))) || (need_s && !s)) return fail(ctx, BP_E_ARG, "bp_vec_op: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) return BP_OK;
+  void *da, *db = nullptr, *dout;
+  CHK(upload(ctx, S_IN0, a, n * 32, &da));
+  if (need_b) CHK(upload(ctx, S_IN1, b, n * 32, &db));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dout));
+  FeArg sa{};
+  if (need_s) sa = to_arg(s);
+  hipError_t e = launch_vec_op(curve, op, (const u32*)da, (const u32*)db, sa, n, (u32*)dout, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "vec_op", e);
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+static int s_vector_common(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_inv, size_t k, u32* d_out) {
+  void *dch, *dchi, *dtab;
+  CHK(upload(ctx, S_IN0, ch, k * 32, &dch));
+  CHK(upload(ctx, S_IN1, ch_inv, k * 32, &dchi));
+  CHK(reserve(ctx, S_TABLE, s_vector_table_elems((int)k) * 32, &dtab));
+  HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  hipError_t e = launch_s_vector(curve, (const u32*)dch, (const u32*)dchi, (int)k, (u32*)dtab, d_out, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "s_vector", e);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+  return BP_OK;
+}
+
+int bp_s_vector_dev(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_inv, size_t k, uint64_t* d_out) {
+  if (!ctx || !d_out || (k && (!ch || !ch_inv))) return fail(ctx, BP_E_ARG, "bp_s_vector_dev: null argument");
+  if (k > 28) return fail(ctx, BP_E_ARG, "bp_s_vector_dev: k > 28");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  CHK(s_vector_common(ctx, curve, ch, ch_inv, k, (u32*)d_out));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  float ms;
+  if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->last_ms[2] = ms;
+  return BP_OK;
+}
+
+int bp_s_vector(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_inv, size_t k, uint64_t* out) {
+  if (!ctx || !out || (k && (!ch || !ch_inv))) return fail(ctx, BP_E_ARG, "bp_s_vector: null argument");
+  if (k > 28) return fail(ctx, BP_E_ARG, "bp_s_vector: k > 28");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  size_t n = (size_t)1 << k;
+  void* dout;
+  CHK(reserve(ctx, S_OUT0, n * 32, &dout));
+  CHK(s_vector_common(ctx, curve, ch, ch_inv, k, (u32*)dout));
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_powers(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* out) {
+  if (!ctx || !x || (n && !out)) return fail(ctx, BP_E_ARG, "bp_powers: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) return BP_OK;
+  void *dtab, *dout;
+  CHK(reserve(ctx, S_TABLE, powers_table_elems(n) * 32, &dtab));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dout));
+  hipError_t e = launch_powers(curve, to_arg(x), n, (u32*)dtab, (u32*)dout, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "powers", e);
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_batch_inverse(bp_ctx* ctx, int curve, int field, uint64_t* v, size_t n) {
+  if (!ctx || (n && !v) || (field != 0 && field != 1)) return fail(ctx, BP_E_ARG, "bp_batch_inverse: bad argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) return BP_OK;
+  void* dv;
+  CHK(upload(ctx, S_IN0, v, n * 32, &dv));
+  hipError_t e = launch_batch_inverse(curve, field, (u32*)dv, n, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "batch_inverse", e);
+  HIPCHK(ctx, hipMemcpyAsync(v, dv, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+// ---- curve-vector kernels -------------------------------------------------------
+
+int bp_fold_generators_dev(bp_ctx* ctx, int curve, const uint64_t* d_lx, const uint64_t* d_ly, const uint8_t* d_linf,
+                           const uint64_t* d_rx, const uint64_t* d_ry, const uint8_t* d_rinf, size_t h,
+                           const uint64_t x[4], const uint64_t y[4], uint64_t* d_out_x, uint64_t* d_out_y,
+                           uint8_t* d_out_inf) {
+  if (!ctx || !x || !y || (h && (!d_lx || !d_ly || !d_rx || !d_ry || !d_out_x || !d_out_y)))
+    return fail(ctx, BP_E_ARG, "bp_fold_generators_dev: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  hipError_t e = launch_fold_generators(curve, (const u32*)d_lx, (const u32*)d_ly, d_linf, (const u32*)d_rx,
+                                        (const u32*)d_ry, d_rinf, h, to_canonical_fr(curve, x),
+                                        to_canonical_fr(curve, y), (u32*)d_out_x, (u32*)d_out_y, d_out_inf,
+                                        ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_generators", e);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  float ms;
+  if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->last_ms[2] = ms;
+  return BP_OK;
+}
+
+int bp_fold_generators(bp_ctx* ctx, int curve, const uint64_t* lx, const uint64_t* ly, const uint8_t* linf,
+                       const uint64_t* rx, const uint64_t* ry, const uint8_t* rinf, size_t h, const uint64_t x[4],
+                       const uint64_t y[4], uint64_t* out_x, uint64_t* out_y, uint8_t* out_inf) {
+  if (!ctx || !x || !y || (h && (!lx || !ly || !rx || !ry || !out_x || !out_y)))
+    return fail(ctx, BP_E_ARG, "bp_fold_generators: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (h == 0) return BP_OK;
+  void *dlx, *dly, *dli = nullptr, *drx, *dry, *dri = nullptr, *dox, *doy, *doi;
+  CHK(upload(ctx, S_IN0, lx, h * 32, &dlx));
+  CHK(upload(ctx, S_IN1, ly, h * 32, &dly));
+  if (linf) CHK(upload(ctx, S_IN2, linf, h, &dli));
+  CHK(upload(ctx, S_IN3, rx, h * 32, &drx));
+  CHK(upload(ctx, S_IN4, ry, h * 32, &dry));
+  if (rinf) CHK(upload(ctx, S_IN5, rinf, h, &dri));
+  CHK(reserve(ctx, S_OUT0, h * 32, &dox));
+  CHK(reserve(ctx, S_OUT1, h * 32, &doy));
+  CHK(reserve(ctx, S_OUT2, h, &doi));
+  hipError_t e = launch_fold_generators(curve, (const u32*)dlx, (const u32*)dly, (const uint8_t*)dli, (const u32*)drx,
+                                        (const u32*)dry, (const uint8_t*)dri, h, to_canonical_fr(curve, x),
+                                        to_canonical_fr(curve, y), (u32*)dox, (u32*)doy, (uint8_t*)doi, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_generators", e);
+  HIPCHK(ctx, hipMemcpyAsync(out_x, dox, h * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out_y, doy, h * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_inf) HIPCHK(ctx, hipMemcpyAsync(out_inf, doi, h, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_scale_points(bp_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py, const uint8_t* pinf,
+                    const uint64_t* s, size_t n, uint64_t* out_x, uint64_t* out_y, uint8_t* out_inf) {
+  if (!ctx || (n && (!px || !py || !s || !out_x || !out_y))) return fail(ctx, BP_E_ARG, "bp_scale_points: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) return BP_OK;
+  void *dx, *dy, *di = nullptr, *ds, *dox, *doy, *doi;
+  CHK(upload(ctx, S_IN0, px, n * 32, &dx));
+  CHK(upload(ctx, S_IN1, py, n * 32, &dy));
+  if (pinf) CHK(upload(ctx, S_IN2, pinf, n, &di));
+  CHK(upload(ctx, S_IN3, s, n * 32, &ds));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dox));
+  CHK(reserve(ctx, S_OUT1, n * 32, &doy));
+  CHK(reserve(ctx, S_OUT2, n, &doi));
+  hipError_t e = launch_scale_points(curve, (const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)ds, n,
+                                     (u32*)dox, (u32*)doy, (uint8_t*)doi, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "scale_points", e);
+  HIPCHK(ctx, hipMemcpyAsync(out_x, dox, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out_y, doy, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_inf) HIPCHK(ctx, hipMemcpyAsync(out_inf, doi, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_normalize_batch(bp_ctx* ctx, int curve, const uint64_t* xyz, size_t n, uint64_t* out_x, uint64_t* out_y,
+                       uint8_t* out_inf) {
+  if (!ctx || (n && (!xyz || !out_x || !out_y))) return fail(ctx, BP_E_ARG, "bp_normalize_batch: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) return BP_OK;
+  void *din, *dox, *doy, *doi;
+  CHK(upload(ctx, S_IN0, xyz, n * 96, &din));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dox));
+  CHK(reserve(ctx, S_OUT1, n * 32, &doy));
+  CHK(reserve(ctx, S_OUT2, n, &doi));
+  hipError_t e = launch_normalize_jac(curve, (const u32*)din, n, (u32*)dox, (u32*)doy, (uint8_t*)doi, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "normalize_batch", e);
+  HIPCHK(ctx, hipMemcpyAsync(out_x, dox, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out_y, doy, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_inf) HIPCHK(ctx, hipMemcpyAsync(out_inf, doi, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+// ---- IPA session -----------------------------------------------------------------
+
+void bp_ipa_free(bp_ipa* s) {
+  if (!s) return;
+  Guard g(s->ctx);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  void* ptrs[] = {s->gx, s->gy, s->ginf, s->hx, s->hy, s->hinf, s->a, s->b};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete s;
+}
+
+int bp_ipa_begin(bp_ctx* ctx, int curve, int variant, const uint64_t* gx, const uint64_t* gy, const uint8_t* ginf,
+                 const uint64_t* hx, const uint64_t* hy, const uint8_t* hinf, const uint64_t* a, const uint64_t* b,
+                 size_t n, bp_ipa** out) {
+  if (!ctx || !out || !gx || !gy || !a || !b) return fail(ctx, BP_E_ARG, "bp_ipa_begin: null argument");
+  if (variant != BP_IPA_BULLETPROOF && variant != BP_IPA_POLYCOMMIT) return fail(ctx, BP_E_ARG, "bp_ipa_begin: bad variant");
+  if (variant == BP_IPA_BULLETPROOF && (!hx || !hy)) return fail(ctx, BP_E_ARG, "bp_ipa_begin: hs required");
+  if (n == 0 || (n & (n - 1))) return fail(ctx, BP_E_ARG, "bp_ipa_begin: n must be a power of two");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  bp_ipa* s = new (std::nothrow) bp_ipa();
+  if (!s) return fail(ctx, BP_E_OOM, "host allocation");
+  memset(s, 0, sizeof *s);
+  s->ctx = ctx;
+  s->curve = curve;
+  s->variant = variant;
+  s->n = n;
+  bool has_h = variant == BP_IPA_BULLETPROOF;
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void** p, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(p, bytes);
+  };
+  alloc((void**)&s->gx, n * 32); alloc((void**)&s->gy, n * 32); alloc((void**)&s->ginf, n);
+  alloc((void**)&s->a, n * 32); alloc((void**)&s->b, n * 32);
+  if (has_h) { alloc((void**)&s->hx, n * 32); alloc((void**)&s->hy, n * 32); alloc((void**)&s->hinf, n); }
+  auto put = [&](void* d, const void* h, size_t bytes) {
+    if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream);
+  };
+  put(s->gx, gx, n * 32); put(s->gy, gy, n * 32);
+  if (e == hipSuccess) e = ginf ? hipMemcpyAsync(s->ginf, ginf, n, hipMemcpyHostToDevice, ctx->stream) : hipMemsetAsync(s->ginf, 0, n, ctx->stream);
+  put(s->a, a, n * 32); put(s->b, b, n * 32);
+  if (has_h) {
+    put(s->hx, hx, n * 32); put(s->hy, hy, n * 32);
+    if (e == hipSuccess) e = hinf ? hipMemcpyAsync(s->hinf, hinf, n, hipMemcpyHostToDevice, ctx->stream) : hipMemsetAsync(s->hinf, 0, n, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    int code = fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "bp_ipa_begin", e);
+    g.lk.unlock();
+    bp_ipa_free(s);
+    return code;
+  }
+  *out = s;
+  return BP_OK;
+}
+
+size_t bp_ipa_len(const bp_ipa* s) { return s ? s->n : 0; }
+
+int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t c_l[4], uint64_t c_r[4]) {
+  if (!s || !l_xyz || !r_xyz || !c_l || !c_r) return BP_E_ARG;
+  bp_ctx* ctx = s->ctx;
+  if (s->n < 2) return fail(ctx, BP_E_STATE, "bp_ipa_round_lr: vectors already folded to length 1");
+  Guard g(ctx);
+  size_t h = s->n / 2;
+  const u32 *a_lo = s->a, *a_hi = s->a + h * 8, *b_lo = s->b, *b_hi = s->b + h * 8;
+  const u32 *gx_lo = s->gx, *gx_hi = s->gx + h * 8, *gy_lo = s->gy, *gy_hi = s->gy + h * 8;
+  const uint8_t *gi_lo = s->ginf, *gi_hi = s->ginf + h;
+  MsmPart none{nullptr, nullptr, nullptr, nullptr, 0};
+  if (s->variant == BP_IPA_BULLETPROOF) {
+    const u32 *hx_lo = s->hx, *hx_hi = s->hx + h * 8, *hy_lo = s->hy, *hy_hi = s->hy + h * 8;
+    const uint8_t *hi_lo = s->hinf, *hi_hi = s->hinf + h;
+    // L: bases g_hi || h_lo, scalars a_lo || b_hi  (src/ipa/mod.rs:44-54)
+    CHK(msm_full(ctx, s->curve, MsmPart{gx_hi, gy_hi, gi_hi, a_lo, h}, MsmPart{hx_lo, hy_lo, hi_lo, b_hi, h}, l_xyz));
+    // R: bases g_lo || h_hi, scalars a_hi || b_lo  (src/ipa/mod.rs:60-70)
+    CHK(msm_full(ctx, s->curve, MsmPart{gx_lo, gy_lo, gi_lo, a_hi, h}, MsmPart{hx_hi, hy_hi, hi_hi, b_lo, h}, r_xyz));
+  } else {
+    // src/poly_commit/mod.rs:78,83
+    CHK(msm_full(ctx, s->curve, MsmPart{gx_hi, gy_hi, gi_hi, a_lo, h}, none, l_xyz));
+    CHK(msm_full(ctx, s->curve, MsmPart{gx_lo, gy_lo, gi_lo, a_hi, h}, none, r_xyz));
+  }
+  CHK(dot_dev(ctx, s->curve, a_lo, b_hi, h, c_l));
+  CHK(dot_dev(ctx, s->curve, a_hi, b_lo, h, c_r));
+  return BP_OK;
+}
+
+int bp_ipa_round_fold(bp_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]) {
+  if (!s || !x || !x_inv) return BP_E_ARG;
+  bp_ctx* ctx = s->ctx;
+  if (s->n < 2) return fail(ctx, BP_E_STATE, "bp_ipa_round_fold: vectors already folded to length 1");
+  Guard g(ctx);
+  size_t h = s->n / 2;
+  FeArg xm = to_arg(x), xim = to_arg(x_inv);
+  FeArg xc = to_canonical_fr(s->curve, x), xic = to_canonical_fr(s->curve, x_inv);
+  hipError_t e;
+  // Outputs overwrite the low halves in place: output i reads only inputs i and i+h.
+  // G' = x^-1*G_lo + x*G_hi (both variants: src/ipa/mod.rs:81, src/poly_commit/mod.rs:102)
+  e = launch_fold_generators(s->curve, s->gx, s->gy, s->ginf, s->gx + h * 8, s->gy + h * 8, s->ginf + h, h, xic, xc,
+                             s->gx, s->gy, s->ginf, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_generators(G)", e);
+  if (s->variant == BP_IPA_BULLETPROOF) {
+    // H' = x*H_lo + x^-1*H_hi (src/ipa/mod.rs:82)
+    e = launch_fold_generators(s->curve, s->hx, s->hy, s->hinf, s->hx + h * 8, s->hy + h * 8, s->hinf + h, h, xc, xic,
+                               s->hx, s->hy, s->hinf, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_generators(H)", e);
+    // a' = a_lo*x + a_hi*x^-1 ; b' = b_lo*x^-1 + b_hi*x (src/ipa/mod.rs:88-89)
+    e = launch_fold_scalars(s->curve, s->a, s->a + h * 8, h, xm, xim, s->a, ctx->stream);
+    if (e == hipSuccess) e = launch_fold_scalars(s->curve, s->b, s->b + h * 8, h, xim, xm, s->b, ctx->stream);
+  } else {
+    // a' = a_hi*u^-1 + a_lo*u ; b' = b_lo*u^-1 + b_hi*u (src/poly_commit/mod.rs:96-97)
+    e = launch_fold_scalars(s->curve, s->a + h * 8, s->a, h, xim, xm, s->a, ctx->stream);
+    if (e == hipSuccess) e = launch_fold_scalars(s->curve, s->b, s->b + h * 8, h, xim, xm, s->b, ctx->stream);
+  }
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_scalars", e);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  s->n = h;
+  return BP_OK;
+}
+
+int bp_ipa_read(bp_ipa* s, uint64_t* gx, uint64_t* gy, uint8_t* ginf, uint64_t* hx, uint64_t* hy, uint8_t* hinf,
+                uint64_t* a, uint64_t* b) {
+  if (!s) return BP_E_ARG;
+  bp_ctx* ctx = s->ctx;
+  Guard g(ctx);
+  size_t n = s->n;
+  struct { void* h; const void* d; size_t bytes; } cp[] = {
+      {gx, s->gx, n * 32}, {gy, s->gy, n * 32}, {ginf, s->ginf, n}, {hx, s->hx, n * 32},
+      {hy, s->hy, n * 32}, {hinf, s->hinf, n}, {a, s->a, n * 32}, {b, s->b, n * 32}};
+  for (auto& c : cp) {
+    if (!c.h) continue;
+    if (!c.d) return fail(ctx, BP_E_ARG, "bp_ipa_read: session has no H vector");
+    HIPCHK(ctx, hipMemcpyAsync(c.h, c.d, c.bytes, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+// ---- measurement helpers -----------------------------------------------------------
+
+int bp_bench_int_mad_peak(bp_ctx* ctx, int iters, double* mac_per_s) {
+  if (!ctx || !mac_per_s || iters < 1) return fail(ctx, BP_E_ARG, "bp_bench_int_mad_peak: bad argument");
+  Guard g(ctx);
+  void* sink;
+  CHK(reserve(ctx, S_SMALL, 256, &sink));
+  hipDeviceProp_t prop;
+  HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  int blocks = prop.multiProcessorCount * 8;
+  hipError_t e = launch_int_mad_peak(iters, (u32*)sink, blocks, ctx->stream);  // warm-up
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "int_mad_peak", e);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  e = launch_int_mad_peak(iters, (u32*)sink, blocks, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "int_mad_peak", e);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+  double macs = (double)blocks * 256.0 * (double)iters * 64.0;
+  *mac_per_s = macs / ((double)ms * 1e-3);
+  return BP_OK;
+}
+
+int bp_last_kernel_ms(bp_ctx* ctx, int group, float* ms) {
+  if (!ctx || !ms || group < 0 || group > 2) return fail(ctx, BP_E_ARG, "bp_last_kernel_ms: bad argument");
+  Guard g(ctx);
+  *ms = ctx->last_ms[group];
+  return BP_OK;
+}
+
+}  // extern "C"

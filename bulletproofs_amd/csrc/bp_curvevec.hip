@@ -1,0 +1,152 @@
+// Curve-vector kernels for gfx950: generator fold, per-point scaling, batch
+// normalisation.  One thread owns one output point; the double-and-add schedule
+// of the generator fold is shared by all lanes (the two scalars are the same for
+// every output), so there is no divergence on the common path.
+#include "bp_curve.h"
+#include "bp_internal.h"
+
+namespace bp {
+
+#define DISPATCH_CURVE(curve, STMT)              \
+  switch (curve) {                               \
+    case BP_SECP256K1: {                         \
+      using C = Secp256k1;                       \
+      STMT;                                      \
+    } break;                                     \
+    case BP_VESTA: {                             \
+      using C = Vesta;                           \
+      STMT;                                      \
+    } break;                                     \
+    default:                                     \
+      return hipErrorInvalidValue;               \
+  }
+
+// out[i] = x*L[i] + y*R[i]  (src/ipa/mod.rs:215-227).  x, y arrive as canonical
+// 256-bit integers; Shamir's trick over their joint bits with the per-thread
+// table {L, R, L+R} (L+R normalised to affine so every add is a mixed add).
+template <class C>
+__global__ __launch_bounds__(128) void k_fold_generators(
+    const u32* __restrict__ lx, const u32* __restrict__ ly, const uint8_t* __restrict__ linf,
+    const u32* __restrict__ rx, const u32* __restrict__ ry, const uint8_t* __restrict__ rinf,
+    size_t h, FeArg xs, FeArg ys, u32* __restrict__ ox, u32* __restrict__ oy,
+    uint8_t* __restrict__ oinf) {
+  using F = typename C::Fq;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h) return;
+  bool l_inf = linf && linf[i];
+  bool r_inf = rinf && rinf[i];
+  Fe Lx = fe_load(lx + i * 8), Ly = fe_load(ly + i * 8);
+  Fe Rx = fe_load(rx + i * 8), Ry = fe_load(ry + i * 8);
+  // T = L + R in affine (or flagged identity)
+  Fe Tx, Ty;
+  bool t_inf;
+  {
+    Jac t = jac_identity<F>();
+    if (!l_inf) jac_madd<F>(t, Lx, Ly);
+    if (!r_inf) jac_madd<F>(t, Rx, Ry);
+    t_inf = jac_to_affine<F>(t, Tx, Ty);
+  }
+  Jac acc = jac_identity<F>();
+  for (int w = 7; w >= 0; w--) {
+    u32 xw = xs.v[w], yw = ys.v[w];
+    for (int b = 31; b >= 0; b--) {
+      acc = jac_dbl<F>(acc);
+      u32 sel = ((xw >> b) & 1) | (((yw >> b) & 1) << 1);
+      if (sel) {  // wave-uniform
+        Fe qx = fe_select(sel == 1, Lx, fe_select(sel == 2, Rx, Tx));
+        Fe qy = fe_select(sel == 1, Ly, fe_select(sel == 2, Ry, Ty));
+        bool q_inf = sel == 1 ? l_inf : (sel == 2 ? r_inf : t_inf);
+        if (!q_inf) jac_madd<F>(acc, qx, qy);
+      }
+    }
+  }
+  Fe X, Y;
+  bool inf = jac_to_affine<F>(acc, X, Y);
+  fe_store(ox + i * 8, X);
+  fe_store(oy + i * 8, Y);
+  if (oinf) oinf[i] = inf ? 1 : 0;
+}
+
+hipError_t launch_fold_generators(int curve, const u32* lx, const u32* ly, const uint8_t* linf,
+                                  const u32* rx, const u32* ry, const uint8_t* rinf, size_t h,
+                                  FeArg x_canon, FeArg y_canon, u32* ox, u32* oy, uint8_t* oinf,
+                                  hipStream_t st) {
+  if (h == 0) return hipSuccess;
+  unsigned blocks = (unsigned)((h + 127) / 128);
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_fold_generators<C>, dim3(blocks), dim3(128), 0, st, lx,
+                                           ly, linf, rx, ry, rinf, h, x_canon, y_canon, ox, oy, oinf));
+  return hipGetLastError();
+}
+
+// out[i] = s[i] * P[i]  (src/range/aggregate.rs:148-153).  Per-point scalars, so
+// the add branch diverges; the doublings stay uniform.
+template <class C>
+__global__ __launch_bounds__(128) void k_scale_points(const u32* __restrict__ px,
+                                                      const u32* __restrict__ py,
+                                                      const uint8_t* __restrict__ pinf,
+                                                      const u32* __restrict__ s, size_t n,
+                                                      u32* __restrict__ ox, u32* __restrict__ oy,
+                                                      uint8_t* __restrict__ oinf) {
+  using F = typename C::Fq;
+  using Fr = typename C::Fr;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool p_inf = pinf && pinf[i];
+  Fe Px = fe_load(px + i * 8), Py = fe_load(py + i * 8);
+  Fe k = fe_from_mont<Fr>(fe_load(s + i * 8));
+  Jac acc = jac_identity<F>();
+  if (!p_inf) {
+    for (int w = 7; w >= 0; w--) {
+      u32 kw = k.v[w];
+      for (int b = 31; b >= 0; b--) {
+        acc = jac_dbl<F>(acc);
+        if ((kw >> b) & 1) jac_madd<F>(acc, Px, Py);
+      }
+    }
+  }
+  Fe X, Y;
+  bool inf = jac_to_affine<F>(acc, X, Y);
+  fe_store(ox + i * 8, X);
+  fe_store(oy + i * 8, Y);
+  if (oinf) oinf[i] = inf ? 1 : 0;
+}
+
+hipError_t launch_scale_points(int curve, const u32* px, const u32* py, const uint8_t* pinf,
+                               const u32* s, size_t n, u32* ox, u32* oy, uint8_t* oinf,
+                               hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  unsigned blocks = (unsigned)((n + 127) / 128);
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_scale_points<C>, dim3(blocks), dim3(128), 0, st, px, py,
+                                           pinf, s, n, ox, oy, oinf));
+  return hipGetLastError();
+}
+
+// Jacobian (X,Y,Z interleaved, 24 u32 per point) -> affine planes
+template <class C>
+__global__ __launch_bounds__(128) void k_normalize_jac(const u32* __restrict__ xyz, size_t n,
+                                                       u32* __restrict__ ox, u32* __restrict__ oy,
+                                                       uint8_t* __restrict__ oinf) {
+  using F = typename C::Fq;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Jac p;
+  p.x = fe_load(xyz + i * 24);
+  p.y = fe_load(xyz + i * 24 + 8);
+  p.z = fe_load(xyz + i * 24 + 16);
+  Fe X, Y;
+  bool inf = jac_to_affine<F>(p, X, Y);
+  fe_store(ox + i * 8, X);
+  fe_store(oy + i * 8, Y);
+  if (oinf) oinf[i] = inf ? 1 : 0;
+}
+
+hipError_t launch_normalize_jac(int curve, const u32* xyz, size_t n, u32* ox, u32* oy, uint8_t* oinf,
+                                hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  unsigned blocks = (unsigned)((n + 127) / 128);
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_normalize_jac<C>, dim3(blocks), dim3(128), 0, st, xyz, n,
+                                           ox, oy, oinf));
+  return hipGetLastError();
+}
+
+}  // namespace bp

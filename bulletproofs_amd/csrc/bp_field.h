@@ -1,0 +1,228 @@
+// 256-bit prime-field arithmetic for gfx950, Montgomery form (a*2^256 mod p),
+// eight 32-bit limbs per element held in VGPRs.  The multiply is a CIOS
+// Montgomery product written so that every partial product is one
+// v_mad_u64_u32 (32x32+64 -> 64); there is no floating point and no MFMA use:
+// the work is not a dense contraction.
+//
+// Replaces, on the device, the ark-ff 0.5.0 `Fp<MontBackend<_,4>>` operations
+// the reference reaches through `Field` (src/vector_ops.rs:159-179,
+// src/ipa/mod.rs:229-234).  Memory format is exactly arkworks': four
+// little-endian u64 limbs = eight little-endian u32 limbs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bp_field_consts.h"
+
+namespace bp {
+
+struct Fe {
+  uint32_t v[8];
+};
+
+#define BP_DEV __host__ __device__ __forceinline__
+
+BP_DEV Fe fe_load(const uint32_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 lo = q[0], hi = q[1];
+  Fe r;
+  r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+  r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+  return r;
+}
+
+BP_DEV void fe_store(uint32_t* p, const Fe& a) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+  q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+BP_DEV Fe fe_zero() {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = 0;
+  return r;
+}
+
+template <class F>
+BP_DEV Fe fe_one() {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = F::one(i);
+  return r;
+}
+
+BP_DEV bool fe_is_zero(const Fe& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.v[i];
+  return o == 0;
+}
+
+BP_DEV bool fe_eq(const Fe& a, const Fe& b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+  return o == 0;
+}
+
+BP_DEV Fe fe_select(bool c, const Fe& a, const Fe& b) {  // c ? a : b
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+
+// r = a - p, returns borrow (1 when a < p)
+template <class F>
+BP_DEV uint32_t fe_sub_mod_raw(Fe& r, const Fe& a) {
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (int64_t)a.v[i] - (int64_t)F::mod(i);
+    r.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  return (uint32_t)(c & 1);
+}
+
+// reduce a value known to be < 2p (carry = bit 256 of the value)
+template <class F>
+BP_DEV Fe fe_reduce_once(const Fe& a, uint32_t carry) {
+  Fe d;
+  uint32_t borrow = fe_sub_mod_raw<F>(d, a);
+  bool use_d = F::kFullWidth ? (carry != 0 || borrow == 0) : (borrow == 0);
+  return fe_select(use_d, d, a);
+}
+
+template <class F>
+BP_DEV Fe fe_add(const Fe& a, const Fe& b) {
+  Fe s;
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (uint64_t)a.v[i] + b.v[i];
+    s.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  return fe_reduce_once<F>(s, (uint32_t)c);
+}
+
+template <class F>
+BP_DEV Fe fe_sub(const Fe& a, const Fe& b) {
+  Fe d;
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (int64_t)a.v[i] - (int64_t)b.v[i];
+    d.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  uint32_t mask = (uint32_t)c;  // 0 or 0xffffffff when a < b
+  uint64_t k = 0;
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    k += (uint64_t)d.v[i] + (F::mod(i) & mask);
+    r.v[i] = (uint32_t)k;
+    k >>= 32;
+  }
+  return r;
+}
+
+template <class F>
+BP_DEV Fe fe_neg(const Fe& a) {
+  Fe r;
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (int64_t)F::mod(i) - (int64_t)a.v[i];
+    r.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  return fe_select(fe_is_zero(a), a, r);
+}
+
+template <class F>
+BP_DEV Fe fe_dbl(const Fe& a) {
+  Fe s;
+  uint32_t carry = a.v[7] >> 31;
+#pragma unroll
+  for (int i = 7; i > 0; i--) s.v[i] = (a.v[i] << 1) | (a.v[i - 1] >> 31);
+  s.v[0] = a.v[0] << 1;
+  return fe_reduce_once<F>(s, carry);
+}
+
+// Montgomery product a*b*2^-256 mod p.  CIOS, 8 outer steps; each step is a
+// row of 8 multiply-accumulates for a*b[i] and a row of 8 for m*p.
+template <class F>
+BP_DEV Fe fe_mul(const Fe& a, const Fe& b) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t c = 0;
+    const uint32_t bi = b.v[i];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      uint64_t x = (uint64_t)a.v[j] * bi + t[j] + c;
+      t[j] = (uint32_t)x;
+      c = x >> 32;
+    }
+    uint64_t top = (uint64_t)t[8] + c;
+    const uint32_t m = t[0] * F::kInv32;
+    c = ((uint64_t)m * F::mod(0) + t[0]) >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      uint64_t x = (uint64_t)m * F::mod(j) + t[j] + c;
+      t[j - 1] = (uint32_t)x;
+      c = x >> 32;
+    }
+    top += c;
+    t[7] = (uint32_t)top;
+    t[8] = (uint32_t)(top >> 32);
+  }
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return fe_reduce_once<F>(r, t[8]);
+}
+
+template <class F>
+BP_DEV Fe fe_sqr(const Fe& a) {
+  return fe_mul<F>(a, a);
+}
+
+// Montgomery form -> canonical integer (multiply by 1)
+template <class F>
+BP_DEV Fe fe_from_mont(const Fe& a) {
+  Fe one = fe_zero();
+  one.v[0] = 1;
+  return fe_mul<F>(a, one);
+}
+
+template <class F>
+BP_DEV Fe fe_to_mont(const Fe& a) {
+  Fe r2;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r2.v[i] = F::r2(i);
+  return fe_mul<F>(a, r2);
+}
+
+// a^(p-2): Fermat inverse; 0 maps to 0 (the convention of ark-ff's
+// batch_inversion, which leaves zeros untouched).
+template <class F>
+__host__ __device__ __noinline__ Fe fe_inv(const Fe& a) {
+  Fe r = fe_one<F>();
+  for (int i = 7; i >= 0; i--) {
+    uint32_t w = F::pm2(i);
+    for (int b = 31; b >= 0; b--) {
+      r = fe_sqr<F>(r);
+      if ((w >> b) & 1) r = fe_mul<F>(r, a);
+    }
+  }
+  return r;
+}
+
+}  // namespace bp

@@ -1,0 +1,99 @@
+// Internal host-side declarations shared by the translation units of libbp_gpu.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/bp_gpu.h"
+
+namespace bp {
+
+typedef uint32_t u32;
+
+struct FeArg {  // field element passed by value as a kernel argument
+  u32 v[8];
+};
+
+// ---- streaming field-vector kernels (bp_vec.hip); all pointers are device ----
+// field: 0 = scalar field Fr, 1 = base field Fq
+hipError_t launch_fold_scalars(int curve, const u32* l, const u32* r, size_t h, FeArg x, FeArg y,
+                               u32* out, hipStream_t st);
+// b may be null (plain sum).  partials: >= kDotBlocks*8 u32.  out: 8 u32.
+constexpr int kDotBlocks = 1024;
+hipError_t launch_inner_product(int curve, const u32* a, const u32* b, size_t n, u32* partials,
+                                u32* out, hipStream_t st);
+hipError_t launch_vec_op(int curve, int op, const u32* a, const u32* b, FeArg s, size_t n, u32* out,
+                         hipStream_t st);
+// ch, ch_inv: k elements each; table: >= (2^lo + 2^(k-lo)) * 8 u32 with lo = min(k, 8)
+hipError_t launch_s_vector(int curve, const u32* ch, const u32* ch_inv, int k, u32* table, u32* out,
+                           hipStream_t st);
+size_t s_vector_table_elems(int k);
+// table: >= (256 + ceil(n/256)) * 8 u32
+hipError_t launch_powers(int curve, FeArg x, size_t n, u32* table, u32* out, hipStream_t st);
+size_t powers_table_elems(size_t n);
+hipError_t launch_batch_inverse(int curve, int field, u32* v, size_t n, hipStream_t st);
+hipError_t launch_int_mad_peak(int iters, u32* sink, int blocks, hipStream_t st);
+
+// ---- curve-vector kernels (bp_curvevec.hip) ----
+// scalars are canonical (non-Montgomery) little-endian 256-bit integers here
+hipError_t launch_fold_generators(int curve, const u32* lx, const u32* ly, const uint8_t* linf,
+                                  const u32* rx, const u32* ry, const uint8_t* rinf, size_t h,
+                                  FeArg x_canon, FeArg y_canon, u32* ox, u32* oy, uint8_t* oinf,
+                                  hipStream_t st);
+// s: Montgomery-form scalars, one per point
+hipError_t launch_scale_points(int curve, const u32* px, const u32* py, const uint8_t* pinf,
+                               const u32* s, size_t n, u32* ox, u32* oy, uint8_t* oinf,
+                               hipStream_t st);
+hipError_t launch_normalize_jac(int curve, const u32* xyz, size_t n, u32* ox, u32* oy, uint8_t* oinf,
+                                hipStream_t st);
+
+// ---- MSM (bp_msm.hip) ----
+struct MsmPart {
+  const u32* x;
+  const u32* y;
+  const uint8_t* inf;  // may be null
+  const u32* s;        // Montgomery-form scalars
+  size_t n;
+};
+
+struct MsmPlan {
+  int c;          // window bits
+  int n_windows;  // W
+  u32 n_buckets;  // per window = 2^(c-1)
+  size_t n_total; // points over both parts
+  size_t entries; // W * n_total
+  // workspace sizes in bytes
+  size_t keys_bytes, sort_tmp_bytes, bounds_bytes, bucket_bytes, seg_bytes, win_bytes;
+  int seg_len;    // buckets per reduction segment
+  u32 n_segs;     // per window
+};
+
+int msm_choose_window(size_t n);
+hipError_t msm_make_plan(size_t n_total, int c_override, MsmPlan* plan);
+
+struct MsmWorkspace {
+  u32* keys_a;
+  u32* keys_b;
+  u32* vals_a;
+  u32* vals_b;
+  void* sort_tmp;
+  u32* bucket_start;  // (W*NB + 2)
+  u32* bucket_end;
+  u32* buckets;       // XYZZ SoA: 4 planes * (W*NB) * 8 u32
+  u32* segs;          // XYZZ AoS: W * n_segs * 32 u32
+  u32* windows;       // XYZZ AoS: W * 32 u32
+};
+
+// Runs digits -> sort -> bucket accumulation -> bucket reduction; leaves W window
+// sums (XYZZ, 32 u32 each) in ws.windows.  ev_acc0/ev_acc1 (optional) bracket the
+// accumulation kernel.
+hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPlan& plan,
+                   const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1);
+// sums n_parts arrays of n_windows XYZZ points window by window into out (n_windows XYZZ)
+hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int n_windows, u32* out,
+                                 hipStream_t st);
+
+}  // namespace bp

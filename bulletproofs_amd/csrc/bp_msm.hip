@@ -1,0 +1,322 @@
+// Multi-scalar multiplication for gfx950: Pippenger's bucket method with signed
+// c-bit digits.
+//   1. k_digits      scalars: Montgomery -> integer -> W signed digits; emits one
+//                    (bucket key, point index | sign) pair per point and window
+//   2. radix sort    pairs by bucket key (rocPRIM device radix sort)
+//   3. k_bounds      first/last sorted position of every bucket
+//   4. k_accumulate  bucket sums in XYZZ coordinates with mixed additions
+//   5. k_reduce_*    sum_b b*B_b per window by segmented running sums
+// The W window sums go back to the host, which finishes sum_w 2^(c*w) W_w (a
+// strictly sequential chain of ~256 doublings, slower on a GPU lane than on a CPU
+// core).  Stands in for ark-ec 0.5.0 VariableBaseMSM::msm_unchecked as called at
+// src/msm.rs:84-87 and the direct call sites listed in include/bp_gpu.h.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "bp_curve.h"
+#include "bp_internal.h"
+
+namespace bp {
+
+#define DISPATCH_CURVE(curve, STMT)              \
+  switch (curve) {                               \
+    case BP_SECP256K1: {                         \
+      using C = Secp256k1;                       \
+      constexpr int kBits = 256;                 \
+      (void)kBits;                               \
+      STMT;                                      \
+    } break;                                     \
+    case BP_VESTA: {                             \
+      using C = Vesta;                           \
+      constexpr int kBits = 255;                 \
+      (void)kBits;                               \
+      STMT;                                      \
+    } break;                                     \
+    default:                                     \
+      return hipErrorInvalidValue;               \
+  }
+
+static inline int ilog2_floor(size_t n) {
+  int l = 0;
+  while (n >>= 1) l++;
+  return l;
+}
+
+int msm_choose_window(size_t n) {
+  if (n <= 1) return 4;
+  int c = ilog2_floor(n) - 3;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  return c;
+}
+
+static int key_bits_for(u32 max_key) {
+  int b = 1;
+  while ((1ull << b) <= max_key) b++;
+  return b;
+}
+
+hipError_t msm_make_plan(size_t n_total, int c_override, MsmPlan* plan) {
+  MsmPlan p{};
+  p.c = (c_override >= 2 && c_override <= 20) ? c_override : msm_choose_window(n_total);
+  // enough windows for a 256-bit scalar plus the carry of the signed recoding
+  p.n_windows = (257 + p.c - 1) / p.c;
+  p.n_buckets = 1u << (p.c - 1);
+  p.n_total = n_total;
+  p.entries = (size_t)p.n_windows * n_total;
+  if (p.entries >= (1ull << 31)) return hipErrorInvalidValue;
+  p.seg_len = p.n_buckets < 16 ? (int)p.n_buckets : 16;
+  p.n_segs = p.n_buckets / p.seg_len;
+  size_t nbt = (size_t)p.n_windows * p.n_buckets;
+  p.keys_bytes = ((p.entries * sizeof(u32)) + 255) & ~(size_t)255;
+  p.bounds_bytes = ((nbt + 2) * sizeof(u32) + 255) & ~(size_t)255;
+  p.bucket_bytes = nbt * 4 * 32;
+  p.seg_bytes = (size_t)p.n_windows * p.n_segs * 128;
+  p.win_bytes = (size_t)p.n_windows * 128;
+  size_t tmp = 0;
+  u32 max_key = (u32)nbt;
+  hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
+      nullptr, tmp, nullptr, nullptr, nullptr, nullptr, p.entries ? p.entries : 1, 0,
+      key_bits_for(max_key), 0, false);
+  if (e != hipSuccess) return e;
+  p.sort_tmp_bytes = (tmp + 255) & ~(size_t)255;
+  *plan = p;
+  return hipSuccess;
+}
+
+// ---- 1. digits --------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, const uint8_t* __restrict__ inf0,
+                                                size_t n0, const u32* __restrict__ s1,
+                                                const uint8_t* __restrict__ inf1, size_t n1, int c,
+                                                int n_windows, u32 n_buckets, u32* __restrict__ keys,
+                                                u32* __restrict__ vals) {
+  using Fr = typename C::Fr;
+  size_t n = n0 + n1;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32* sp = i < n0 ? s0 + i * 8 : s1 + (i - n0) * 8;
+  bool is_inf = i < n0 ? (inf0 && inf0[i]) : (inf1 && inf1[i - n0]);
+  Fe k = fe_from_mont<Fr>(fe_load(sp));
+  const u32 invalid = (u32)n_windows * n_buckets;
+  const u32 half = 1u << (c - 1);
+  const u32 mask = (1u << c) - 1;
+  u32 carry = 0;
+  for (int w = 0; w < n_windows; w++) {
+    int bit = w * c;
+    int limb = bit >> 5, sh = bit & 31;
+    u32 raw = 0;
+    if (limb < 8) {
+      // dynamic limb index: select without scratch
+      u32 lo = 0, hi = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        lo = (t == limb) ? k.v[t] : lo;
+        hi = (t == limb + 1) ? k.v[t] : hi;
+      }
+      unsigned long long two = ((unsigned long long)hi << 32) | lo;
+      raw = (u32)(two >> sh) & mask;
+    }
+    u32 v = raw + carry;
+    u32 key, val;
+    if (v > half) {
+      carry = 1;
+      u32 mag = (1u << c) - v;  // |v - 2^c|
+      key = mag ? (u32)w * n_buckets + (mag - 1) : invalid;  // v == 2^c: digit 0, carry 1
+      val = (u32)i | 0x80000000u;
+    } else {
+      carry = 0;
+      key = v ? (u32)w * n_buckets + (v - 1) : invalid;
+      val = (u32)i;
+    }
+    if (is_inf) key = invalid;
+    keys[(size_t)w * n + i] = key;
+    vals[(size_t)w * n + i] = val;
+  }
+}
+
+// ---- 3. bucket bounds ---------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ keys, size_t entries,
+                                                u32* __restrict__ start, u32* __restrict__ end) {
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= entries) return;
+  u32 k = keys[p];
+  if (p == 0 || keys[p - 1] != k) start[k] = (u32)p;
+  if (p + 1 == entries || keys[p + 1] != k) end[k] = (u32)(p + 1);
+}
+
+// ---- 4. bucket accumulation -----------------------------------------------------
+BP_DEV void xyzz_store_soa(u32* base, size_t nbt, size_t b, const Xyzz& p) {
+  fe_store(base + (0 * nbt + b) * 8, p.x);
+  fe_store(base + (1 * nbt + b) * 8, p.y);
+  fe_store(base + (2 * nbt + b) * 8, p.zz);
+  fe_store(base + (3 * nbt + b) * 8, p.zzz);
+}
+BP_DEV Xyzz xyzz_load_soa(const u32* base, size_t nbt, size_t b) {
+  Xyzz p;
+  p.x = fe_load(base + (0 * nbt + b) * 8);
+  p.y = fe_load(base + (1 * nbt + b) * 8);
+  p.zz = fe_load(base + (2 * nbt + b) * 8);
+  p.zzz = fe_load(base + (3 * nbt + b) * 8);
+  return p;
+}
+BP_DEV void xyzz_store_aos(u32* p32, const Xyzz& p) {
+  fe_store(p32, p.x);
+  fe_store(p32 + 8, p.y);
+  fe_store(p32 + 16, p.zz);
+  fe_store(p32 + 24, p.zzz);
+}
+BP_DEV Xyzz xyzz_load_aos(const u32* p32) {
+  Xyzz p;
+  p.x = fe_load(p32);
+  p.y = fe_load(p32 + 8);
+  p.zz = fe_load(p32 + 16);
+  p.zzz = fe_load(p32 + 24);
+  return p;
+}
+
+template <class C>
+__global__ __launch_bounds__(128) void k_accumulate(const u32* __restrict__ x0, const u32* __restrict__ y0,
+                                                    size_t n0, const u32* __restrict__ x1,
+                                                    const u32* __restrict__ y1,
+                                                    const u32* __restrict__ vals,
+                                                    const u32* __restrict__ start,
+                                                    const u32* __restrict__ end, size_t nbt,
+                                                    u32* __restrict__ buckets) {
+  using F = typename C::Fq;
+  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbt) return;
+  u32 s = start[b], e = end[b];
+  Xyzz acc = xyzz_identity<F>();
+  for (u32 p = s; p < e; p++) {
+    u32 v = vals[p];
+    size_t idx = v & 0x7fffffffu;
+    const u32* px = idx < n0 ? x0 + idx * 8 : x1 + (idx - n0) * 8;
+    const u32* py = idx < n0 ? y0 + idx * 8 : y1 + (idx - n0) * 8;
+    Fe qx = fe_load(px);
+    Fe qy = fe_load(py);
+    if (v >> 31) qy = fe_neg<F>(qy);
+    xyzz_madd<F>(acc, qx, qy);
+  }
+  xyzz_store_soa(buckets, nbt, b, acc);
+}
+
+// ---- 5. bucket reduction ----------------------------------------------------------
+// Window value = sum_{j=0}^{NB-1} (j+1)*B_j.  A thread takes seg_len consecutive
+// buckets: T = sum (j-j0+1)*B_j by a running sum, S = sum B_j, and emits
+// T + j0*S (j0*S by double-and-add on a < 2^19 multiplier).
+template <class C>
+__global__ __launch_bounds__(128) void k_reduce_segments(const u32* __restrict__ buckets, size_t nbt,
+                                                         u32 n_buckets, int seg_len, u32 n_segs,
+                                                         int n_windows, u32* __restrict__ segs) {
+  using F = typename C::Fq;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n_windows * n_segs) return;
+  u32 w = (u32)(t / n_segs), sg = (u32)(t % n_segs);
+  u32 j0 = sg * (u32)seg_len;
+  size_t base = (size_t)w * n_buckets + j0;
+  Xyzz run = xyzz_identity<F>(), acc = xyzz_identity<F>();
+  for (int j = seg_len - 1; j >= 0; j--) {
+    Xyzz bk = xyzz_load_soa(buckets, nbt, base + j);
+    xyzz_add<F>(run, bk);
+    xyzz_add<F>(acc, run);
+  }
+  if (j0 != 0 && !xyzz_is_identity(run)) {
+    Xyzz m = xyzz_identity<F>();
+    for (int b = 31 - __clz(j0); b >= 0; b--) {
+      m = xyzz_dbl<F>(m);
+      if ((j0 >> b) & 1) xyzz_add<F>(m, run);
+    }
+    xyzz_add<F>(acc, m);
+  }
+  xyzz_store_aos(segs + t * 32, acc);
+}
+
+// one block per window: sum of n_segs XYZZ points
+template <class C>
+__global__ __launch_bounds__(256) void k_reduce_windows(const u32* __restrict__ segs, u32 n_segs,
+                                                        u32* __restrict__ windows) {
+  using F = typename C::Fq;
+  __shared__ u32 lds[256 * 32];
+  u32 w = blockIdx.x;
+  Xyzz acc = xyzz_identity<F>();
+  for (u32 s = threadIdx.x; s < n_segs; s += blockDim.x) {
+    Xyzz v = xyzz_load_aos(segs + ((size_t)w * n_segs + s) * 32);
+    xyzz_add<F>(acc, v);
+  }
+  xyzz_store_aos(lds + threadIdx.x * 32, acc);
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      Xyzz o = xyzz_load_aos(lds + (threadIdx.x + off) * 32);
+      xyzz_add<F>(acc, o);
+      xyzz_store_aos(lds + threadIdx.x * 32, acc);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) xyzz_store_aos(windows + (size_t)w * 32, acc);
+}
+
+// window-wise sum over parts (multi-GPU combine): out[w] = sum_p in[p][w]
+template <class C>
+__global__ __launch_bounds__(64) void k_window_combine(const u32* __restrict__ in, int n_parts,
+                                                       int n_windows, u32* __restrict__ out) {
+  using F = typename C::Fq;
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_windows) return;
+  Xyzz acc = xyzz_identity<F>();
+  for (int p = 0; p < n_parts; p++) {
+    Xyzz v = xyzz_load_aos(in + ((size_t)p * n_windows + w) * 32);
+    xyzz_add<F>(acc, v);
+  }
+  xyzz_store_aos(out + (size_t)w * 32, acc);
+}
+
+hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int n_windows, u32* out,
+                                 hipStream_t st) {
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_window_combine<C>, dim3((n_windows + 63) / 64), dim3(64),
+                                           0, st, windows, n_parts, n_windows, out));
+  return hipGetLastError();
+}
+
+hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPlan& plan,
+                   const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
+  const size_t n = plan.n_total;
+  const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
+  hipError_t e;
+  if (n == 0) {
+    // all windows = identity (zz = 0)
+    return hipMemsetAsync(ws.windows, 0, plan.win_bytes, st);
+  }
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_digits<C>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                                           st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, plan.c,
+                                           plan.n_windows, plan.n_buckets, ws.keys_a, ws.vals_a));
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  size_t tmp = plan.sort_tmp_bytes;
+  e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
+      ws.sort_tmp, tmp, ws.keys_a, ws.keys_b, ws.vals_a, ws.vals_b, plan.entries, 0,
+      key_bits_for((u32)nbt), st, false);
+  if (e != hipSuccess) return e;
+  if ((e = hipMemsetAsync(ws.bucket_start, 0, plan.bounds_bytes, st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(ws.bucket_end, 0, plan.bounds_bytes, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_bounds, dim3((unsigned)((plan.entries + 255) / 256)), dim3(256), 0, st, ws.keys_b,
+                     plan.entries, ws.bucket_start, ws.bucket_end);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (ev_acc0 && (e = hipEventRecord(ev_acc0, st)) != hipSuccess) return e;
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)((nbt + 127) / 128)), dim3(128),
+                                           0, st, p0.x, p0.y, p0.n, p1.x, p1.y, ws.vals_b,
+                                           ws.bucket_start, ws.bucket_end, nbt, ws.buckets));
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;
+  size_t nseg_threads = (size_t)plan.n_windows * plan.n_segs;
+  DISPATCH_CURVE(curve, {
+    hipLaunchKernelGGL(k_reduce_segments<C>, dim3((unsigned)((nseg_threads + 127) / 128)), dim3(128), 0, st,
+                       ws.buckets, nbt, plan.n_buckets, plan.seg_len, plan.n_segs, plan.n_windows,
+                       ws.segs);
+    hipLaunchKernelGGL(k_reduce_windows<C>, dim3(plan.n_windows), dim3(256), 0, st, ws.segs, plan.n_segs,
+                       ws.windows);
+  });
+  return hipGetLastError();
+}
+
+}  // namespace bp

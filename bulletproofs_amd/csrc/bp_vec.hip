@@ -1,0 +1,360 @@
+// Streaming field-vector kernels for gfx950: scalar fold, inner product / sum,
+// lane-wise ops, s-vector, powers, batch inverse, and the integer-MAC peak probe.
+// One 256-bit element = 32 contiguous bytes; a wave reads/writes 2 KiB runs.
+#include "bp_field.h"
+#include "bp_internal.h"
+
+namespace bp {
+
+#define DISPATCH_FR(curve, STMT)                 \
+  switch (curve) {                               \
+    case BP_SECP256K1: {                         \
+      using F = Secp256k1Fr;                     \
+      STMT;                                      \
+    } break;                                     \
+    case BP_VESTA: {                             \
+      using F = VestaFr;                         \
+      STMT;                                      \
+    } break;                                     \
+    default:                                     \
+      return hipErrorInvalidValue;               \
+  }
+
+BP_DEV Fe arg_to_fe(const FeArg& a) {
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = a.v[i];
+  return r;
+}
+
+// ---- fold_scalars: out[i] = l[i]*x + r[i]*y  (src/ipa/mod.rs:229-234) --------
+template <class F>
+__global__ __launch_bounds__(256) void k_fold_scalars(const u32* __restrict__ l,
+                                                      const u32* __restrict__ r, size_t h, FeArg xa,
+                                                      FeArg ya, u32* __restrict__ out) {
+  const Fe x = arg_to_fe(xa), y = arg_to_fe(ya);
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < h; i += stride) {
+    Fe a = fe_load(l + i * 8);
+    Fe b = fe_load(r + i * 8);
+    Fe o = fe_add<F>(fe_mul<F>(a, x), fe_mul<F>(b, y));
+    fe_store(out + i * 8, o);
+  }
+}
+
+hipError_t launch_fold_scalars(int curve, const u32* l, const u32* r, size_t h, FeArg x, FeArg y,
+                               u32* out, hipStream_t st) {
+  if (h == 0) return hipSuccess;
+  unsigned blocks = (unsigned)((h + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_fold_scalars<F>, dim3(blocks), dim3(256), 0, st, l, r, h, x,
+                                        y, out));
+  return hipGetLastError();
+}
+
+// ---- inner product / sum -------------------------------------------------------
+template <class F>
+BP_DEV Fe wave_reduce_add(Fe acc) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Fe o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.v[i] = __shfl_down(acc.v[i], off, 64);
+    acc = fe_add<F>(acc, o);
+  }
+  return acc;
+}
+
+template <class F>
+BP_DEV Fe block_reduce_add(Fe acc, u32* lds /* 4*8 u32 */) {
+  acc = wave_reduce_add<F>(acc);
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) lds[wave * 8 + i] = acc.v[i];
+  }
+  __syncthreads();
+  Fe tot = fe_zero();
+  if (threadIdx.x == 0) {
+    int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; w++) {
+      Fe o;
+#pragma unroll
+      for (int i = 0; i < 8; i++) o.v[i] = lds[w * 8 + i];
+      tot = fe_add<F>(tot, o);
+    }
+  }
+  return tot;
+}
+
+// src/vector_ops.rs:159-171 (b != null) and :173-179 (b == null).  Modular
+// addition is associative, so the tree order gives the left fold's value.
+template <class F>
+__global__ __launch_bounds__(256) void k_dot_partial(const u32* __restrict__ a,
+                                                     const u32* __restrict__ b, size_t n,
+                                                     u32* __restrict__ partials) {
+  __shared__ u32 lds[32];
+  Fe acc = fe_zero();
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  if (b) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      Fe x = fe_load(a + i * 8);
+      Fe y = fe_load(b + i * 8);
+      acc = fe_add<F>(acc, fe_mul<F>(x, y));
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      acc = fe_add<F>(acc, fe_load(a + i * 8));
+  }
+  Fe tot = block_reduce_add<F>(acc, lds);
+  if (threadIdx.x == 0) fe_store(partials + (size_t)blockIdx.x * 8, tot);
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_dot_final(const u32* __restrict__ partials, int count,
+                                                   u32* __restrict__ out) {
+  __shared__ u32 lds[32];
+  Fe acc = fe_zero();
+  for (int i = threadIdx.x; i < count; i += blockDim.x)
+    acc = fe_add<F>(acc, fe_load(partials + (size_t)i * 8));
+  Fe tot = block_reduce_add<F>(acc, lds);
+  if (threadIdx.x == 0) fe_store(out, tot);
+}
+
+hipError_t launch_inner_product(int curve, const u32* a, const u32* b, size_t n, u32* partials,
+                                u32* out, hipStream_t st) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > kDotBlocks) blocks = kDotBlocks;
+  if (blocks < 1) blocks = 1;
+  DISPATCH_FR(curve, {
+    hipLaunchKernelGGL(k_dot_partial<F>, dim3(blocks), dim3(256), 0, st, a, b, n, partials);
+    hipLaunchKernelGGL(k_dot_final<F>, dim3(1), dim3(256), 0, st, partials, blocks, out);
+  });
+  return hipGetLastError();
+}
+
+// ---- lane-wise ops (src/vector_ops.rs:5-125) --------------------------------
+template <class F, int OP>
+__global__ __launch_bounds__(256) void k_vec_op(const u32* __restrict__ a, const u32* __restrict__ b,
+                                                FeArg sa, size_t n, u32* __restrict__ out) {
+  const Fe s = arg_to_fe(sa);
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    Fe x = fe_load(a + i * 8);
+    Fe o;
+    if (OP == BP_VEC_SCALE) {
+      o = fe_mul<F>(s, x);
+    } else {
+      Fe y = fe_load(b + i * 8);
+      if (OP == BP_VEC_ADD) o = fe_add<F>(x, y);
+      if (OP == BP_VEC_SUB) o = fe_sub<F>(x, y);
+      if (OP == BP_VEC_HADAMARD) o = fe_mul<F>(x, y);
+      if (OP == BP_VEC_AXPY) o = fe_add<F>(x, fe_mul<F>(s, y));
+    }
+    fe_store(out + i * 8, o);
+  }
+}
+
+hipError_t launch_vec_op(int curve, int op, const u32* a, const u32* b, FeArg s, size_t n, u32* out,
+                         hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+#define VOP(OPC) \
+  hipLaunchKernelGGL((k_vec_op<F, OPC>), dim3(blocks), dim3(256), 0, st, a, b, s, n, out)
+  DISPATCH_FR(curve, {
+    switch (op) {
+      case BP_VEC_ADD: VOP(BP_VEC_ADD); break;
+      case BP_VEC_SUB: VOP(BP_VEC_SUB); break;
+      case BP_VEC_HADAMARD: VOP(BP_VEC_HADAMARD); break;
+      case BP_VEC_SCALE: VOP(BP_VEC_SCALE); break;
+      case BP_VEC_AXPY: VOP(BP_VEC_AXPY); break;
+      default: return hipErrorInvalidValue;
+    }
+  });
+#undef VOP
+  return hipGetLastError();
+}
+
+// ---- s-vector (src/ipa/mod.rs:134-148, src/poly_commit/mod.rs:194-219) -------
+// s_i = prod_j (bit j of i ? ch[k-1-j] : ch_inv[k-1-j]).  Split i = hi*2^lo + lo:
+// a small table of low-bit products and one of high-bit products, then one
+// multiply and one 32-byte store per output.
+constexpr int kSvecLoBits = 8;
+
+size_t s_vector_table_elems(int k) {
+  int lo = k < kSvecLoBits ? k : kSvecLoBits;
+  return ((size_t)1 << lo) + ((size_t)1 << (k - lo));
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_svec_tables(const u32* __restrict__ ch,
+                                                     const u32* __restrict__ chi, int k, int lo,
+                                                     u32* __restrict__ table) {
+  size_t n_lo = (size_t)1 << lo, n_hi = (size_t)1 << (k - lo);
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_lo + n_hi) return;
+  Fe acc = fe_one<F>();
+  if (t < n_lo) {
+    for (int j = 0; j < lo; j++) {
+      int idx = k - 1 - j;
+      const u32* src = ((t >> j) & 1) ? ch : chi;
+      acc = fe_mul<F>(acc, fe_load(src + (size_t)idx * 8));
+    }
+  } else {
+    size_t hi = t - n_lo;
+    for (int j = lo; j < k; j++) {
+      int idx = k - 1 - j;
+      const u32* src = ((hi >> (j - lo)) & 1) ? ch : chi;
+      acc = fe_mul<F>(acc, fe_load(src + (size_t)idx * 8));
+    }
+  }
+  fe_store(table + t * 8, acc);
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_svec_expand(const u32* __restrict__ table, int k, int lo,
+                                                     u32* __restrict__ out) {
+  size_t n = (size_t)1 << k, n_lo = (size_t)1 << lo;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    Fe a = fe_load(table + (i & (n_lo - 1)) * 8);
+    Fe b = fe_load(table + (n_lo + (i >> lo)) * 8);
+    fe_store(out + i * 8, fe_mul<F>(a, b));
+  }
+}
+
+hipError_t launch_s_vector(int curve, const u32* ch, const u32* ch_inv, int k, u32* table, u32* out,
+                           hipStream_t st) {
+  int lo = k < kSvecLoBits ? k : kSvecLoBits;
+  size_t nt = s_vector_table_elems(k);
+  size_t n = (size_t)1 << k;
+  unsigned tb = (unsigned)((nt + 255) / 256);
+  unsigned eb = (unsigned)((n + 255) / 256);
+  if (eb > 8192) eb = 8192;
+  DISPATCH_FR(curve, {
+    hipLaunchKernelGGL(k_svec_tables<F>, dim3(tb), dim3(256), 0, st, ch, ch_inv, k, lo, table);
+    hipLaunchKernelGGL(k_svec_expand<F>, dim3(eb), dim3(256), 0, st, table, k, lo, out);
+  });
+  return hipGetLastError();
+}
+
+// ---- powers: out[i] = x^i  (src/poly_commit/mod.rs:16-22) --------------------
+size_t powers_table_elems(size_t n) { return 256 + (n + 255) / 256; }
+
+template <class F>
+__global__ __launch_bounds__(256) void k_pow_tables(FeArg xa, size_t n_hi, u32* __restrict__ table) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 256 + n_hi) return;
+  const Fe x = arg_to_fe(xa);
+  unsigned long long e = t < 256 ? t : (t - 256) * 256ull;
+  Fe acc = fe_one<F>();
+  for (int b = 63 - __clzll(e | 1); b >= 0; b--) {
+    acc = fe_sqr<F>(acc);
+    if ((e >> b) & 1) acc = fe_mul<F>(acc, x);
+  }
+  fe_store(table + t * 8, acc);
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_pow_expand(const u32* __restrict__ table, size_t n,
+                                                    u32* __restrict__ out) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    Fe a = fe_load(table + (i & 255) * 8);
+    Fe b = fe_load(table + (256 + (i >> 8)) * 8);
+    fe_store(out + i * 8, fe_mul<F>(a, b));
+  }
+}
+
+hipError_t launch_powers(int curve, FeArg x, size_t n, u32* table, u32* out, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  size_t n_hi = (n + 255) / 256;
+  unsigned tb = (unsigned)((256 + n_hi + 255) / 256);
+  unsigned eb = (unsigned)((n + 255) / 256);
+  if (eb > 8192) eb = 8192;
+  DISPATCH_FR(curve, {
+    hipLaunchKernelGGL(k_pow_tables<F>, dim3(tb), dim3(256), 0, st, x, n_hi, table);
+    hipLaunchKernelGGL(k_pow_expand<F>, dim3(eb), dim3(256), 0, st, table, n, out);
+  });
+  return hipGetLastError();
+}
+
+// ---- batch inverse (ark_ff::batch_inversion: zeros stay zero) -----------------
+// Each thread inverts a run of kInvRun elements with Montgomery's trick:
+// 3 multiplies per element plus one Fermat inversion per run.
+constexpr int kInvRun = 8;
+
+template <class F>
+__global__ __launch_bounds__(128) void k_batch_inverse(u32* __restrict__ v, size_t n) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t base = t * kInvRun;
+  if (base >= n) return;
+  int cnt = (n - base) < (size_t)kInvRun ? (int)(n - base) : kInvRun;
+  Fe pre[kInvRun];
+  Fe acc = fe_one<F>();
+#pragma unroll
+  for (int i = 0; i < kInvRun; i++) {
+    pre[i] = acc;
+    if (i < cnt) {
+      Fe e = fe_load(v + (base + i) * 8);
+      if (!fe_is_zero(e)) acc = fe_mul<F>(acc, e);
+    }
+  }
+  acc = fe_inv<F>(acc);
+#pragma unroll
+  for (int i = kInvRun - 1; i >= 0; i--) {
+    if (i < cnt) {
+      Fe e = fe_load(v + (base + i) * 8);
+      if (!fe_is_zero(e)) {
+        fe_store(v + (base + i) * 8, fe_mul<F>(acc, pre[i]));
+        acc = fe_mul<F>(acc, e);
+      }
+    }
+  }
+}
+
+hipError_t launch_batch_inverse(int curve, int field, u32* v, size_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  size_t threads = (n + kInvRun - 1) / kInvRun;
+  unsigned blocks = (unsigned)((threads + 127) / 128);
+#define BINV(FT) hipLaunchKernelGGL(k_batch_inverse<FT>, dim3(blocks), dim3(128), 0, st, v, n)
+  if (curve == BP_SECP256K1) {
+    if (field == 0) BINV(Secp256k1Fr); else BINV(Secp256k1Fq);
+  } else if (curve == BP_VESTA) {
+    if (field == 0) BINV(VestaFr); else BINV(VestaFq);
+  } else {
+    return hipErrorInvalidValue;
+  }
+#undef BINV
+  return hipGetLastError();
+}
+
+// ---- integer multiply-accumulate peak probe -----------------------------------
+// 16 independent 32x32+64 accumulators per lane, 4 MACs each per iteration.
+__global__ __launch_bounds__(256) void k_int_mad_peak(int iters, u32* __restrict__ sink) {
+  unsigned long long acc[16];
+  u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 977u;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = (unsigned long long)i * 0x9E3779B97F4A7C15ull + a;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc[i] = (unsigned long long)(a + i) * (u32)(b + r) + acc[i];
+    }
+    a += (u32)acc[0];
+    b ^= (u32)(acc[1] >> 32);
+  }
+  unsigned long long x = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) x ^= acc[i];
+  if (x == 0x123456789abcdefull) sink[0] = (u32)x;  // keeps the chain live, practically never taken
+}
+
+hipError_t launch_int_mad_peak(int iters, u32* sink, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL(k_int_mad_peak, dim3(blocks), dim3(256), 0, st, iters, sink);
+  return hipGetLastError();
+}
+
+}  // namespace bp

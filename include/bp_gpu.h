@@ -1,0 +1,214 @@
+/* bp_gpu.h -- C ABI of libbp_gpu.so: the MI355X (gfx950) implementation of the
+ * data-parallel hot path of the l-adic/bulletproofs crate (multi-scalar
+ * multiplication and the inner-product-argument vector kernels).
+ *
+ * The reference has no FFI of its own: the path is reached by static generic
+ * dispatch into arkworks (G::msm_unchecked, G::normalize_batch, Field ops).
+ * Each entry point below names the reference call site(s) (file:line under the
+ * reference root) it stands in for.
+ *
+ * Conventions
+ *  - Field elements: 4 little-endian u64 limbs holding a*2^256 mod p, i.e. the
+ *    in-memory value of ark_ff::Fp<MontBackend<_,4>> (`Fp.0.0`).  "Fr" is the
+ *    curve's scalar field, "Fq" its base field.
+ *  - Affine points: structure of arrays -- x plane (n*4 u64), y plane (n*4 u64),
+ *    infinity plane (n bytes, non-zero = identity; x,y then ignored on input and
+ *    written as 0 on output).  A NULL infinity plane on input means "none".
+ *  - Group results ("xyz"): 12 u64 = Jacobian X,Y,Z (x = X/Z^2, y = Y/Z^3), the
+ *    layout of ark_ec::short_weierstrass::Projective.  Results are normalised:
+ *    Z = 1 (Montgomery one), or (1,1,0) for the identity.
+ *  - Every function returns BP_OK (0) or a negative BP_E_* code; no exception
+ *    crosses the boundary.  bp_last_error() gives the text of the last failure
+ *    on a context.
+ *  - Threading: a bp_ctx serialises its calls with an internal mutex, so any
+ *    host thread may call into any context; use one context per thread (or per
+ *    concurrent rayon task) for overlap.  Host buffers are only read/written
+ *    during the call.  "_dev" variants take device pointers on the context's
+ *    GPU and enqueue on the context's stream; they return after the result
+ *    needed on the host (if any) has arrived, otherwise asynchronously --
+ *    call bp_sync() before reading device outputs from another stream.
+ *  - The library never falls back to a CPU implementation: if no gfx950 device
+ *    is usable bp_init fails with BP_E_HIP.
+ */
+#ifndef BP_GPU_H
+#define BP_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bp_ctx bp_ctx;
+typedef struct bp_bases bp_bases;
+typedef struct bp_ipa bp_ipa;
+
+enum { BP_SECP256K1 = 0, BP_VESTA = 1 };
+
+enum {
+  BP_OK = 0,
+  BP_E_ARG = -1,    /* null pointer, bad size, bad enum */
+  BP_E_CURVE = -2,  /* unsupported curve id */
+  BP_E_HIP = -3,    /* HIP runtime error / no usable device */
+  BP_E_OOM = -4,    /* device or host allocation failed */
+  BP_E_STATE = -5   /* call out of order on a session object */
+};
+
+/* vector op selectors for bp_vec_op: src/vector_ops.rs:5-125 */
+enum { BP_VEC_ADD = 0, BP_VEC_SUB = 1, BP_VEC_HADAMARD = 2, BP_VEC_SCALE = 3, BP_VEC_AXPY = 4 };
+
+/* IPA variants: which half pairs with which challenge differs between
+ * src/ipa/mod.rs:33-95 and src/poly_commit/mod.rs:69-105 */
+enum { BP_IPA_BULLETPROOF = 0, BP_IPA_POLYCOMMIT = 1 };
+
+/* ---- context ------------------------------------------------------------ */
+
+/* One context = one GPU (HIP device ordinal) + one stream + cached workspace. */
+int bp_init(int device, bp_ctx** out);
+void bp_shutdown(bp_ctx* ctx);
+const char* bp_last_error(bp_ctx* ctx);
+int bp_sync(bp_ctx* ctx);
+/* Window width override for MSM (0 = choose from n). */
+int bp_set_msm_window(bp_ctx* ctx, int c);
+
+/* ---- multi-scalar multiplication ----------------------------------------- */
+
+/* sum_i scalars[i] * bases[i].  Stands in for G::msm_unchecked(&bases,&scalars):
+ * src/msm.rs:84-87 (Msm::execute), src/ipa/mod.rs:54,70,206,
+ * src/ipa/types.rs:81,82,105, src/range/mod.rs:77,78,228,
+ * src/range/aggregate.rs:81,82,226,259, src/circuit/mod.rs:60,65,70,
+ * src/poly_commit/mod.rs:78,83,111,159, src/poly_commit/types.rs:141.
+ * Identity bases, zero scalars and repeated bases are allowed; n may be 0. */
+int bp_msm(bp_ctx* ctx, int curve, const uint64_t* bases_x, const uint64_t* bases_y,
+           const uint8_t* bases_inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]);
+
+/* Same with every input already in device memory (scalars: n*4 u64). */
+int bp_msm_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64_t* d_y,
+               const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t out_xyz[12]);
+
+/* Two-part MSM without concatenation: sum over part 0 then part 1.  The shape of
+ * the L/R cross terms (src/ipa/mod.rs:44-54: bases g_hi||h_lo, scalars a_lo||b_hi). */
+int bp_msm2_dev(bp_ctx* ctx, int curve, const uint64_t* d_x0, const uint64_t* d_y0,
+                const uint8_t* d_inf0, const uint64_t* d_s0, size_t n0, const uint64_t* d_x1,
+                const uint64_t* d_y1, const uint8_t* d_inf1, const uint64_t* d_s1, size_t n1,
+                uint64_t out_xyz[12]);
+
+/* Resident bases: the CRS (ipa::types::CRS src/ipa/types.rs:10-14,
+ * poly_commit CRS) is static, so it is uploaded once. */
+int bp_bases_register(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y,
+                      const uint8_t* inf, size_t n, bp_bases** out);
+void bp_bases_free(bp_bases* b);
+size_t bp_bases_len(const bp_bases* b);
+/* MSM over bases[offset .. offset+n) with host scalars (crs.gs[0..n] slices:
+ * src/ipa/types.rs:81-82). */
+int bp_msm_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
+                    const uint64_t* scalars, uint64_t out_xyz[12]);
+
+/* Per-window partial sums of an MSM, left on the device for a multi-GPU combine:
+ * writes *n_windows and *window_bits, and n_windows XYZZ points (4*4 u64 each)
+ * to d_windows (device, capacity >= 64 points).  bp_msm_combine_windows_dev sums
+ * `n_parts` such arrays (laid out part-major, e.g. an all-gather result) window
+ * by window on the device and finishes sum_w 2^(c*w) W_w. */
+int bp_msm_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64_t* d_y,
+                       const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
+                       uint64_t* d_windows, int* n_windows, int* window_bits);
+int bp_msm_combine_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_windows, int n_parts,
+                               int n_windows, int window_bits, uint64_t out_xyz[12]);
+
+/* ---- field-vector kernels (host buffers) --------------------------------- */
+
+/* sum_i a[i]*b[i] in Fr: inner_product, src/vector_ops.rs:159-171. */
+int bp_inner_product(bp_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, size_t n,
+                     uint64_t out[4]);
+/* sum_i a[i]: sum, src/vector_ops.rs:173-179. */
+int bp_sum(bp_ctx* ctx, int curve, const uint64_t* a, size_t n, uint64_t out[4]);
+/* out[i] = l[i]*x + r[i]*y: fold_scalars, src/ipa/mod.rs:229-234 and
+ * src/poly_commit/mod.rs:24-29. */
+int bp_fold_scalars(bp_ctx* ctx, int curve, const uint64_t* l, const uint64_t* r, size_t h,
+                    const uint64_t x[4], const uint64_t y[4], uint64_t* out);
+/* lane-wise add/sub/hadamard (a op b), scale (s*a), axpy (a + s*b):
+ * VectorOps adaptors src/vector_ops.rs:5-125; Msm::scale src/msm.rs:50-54;
+ * the alpha^i-weighted sum of fold_todos_witness src/poly_commit/mod.rs:228-244. */
+int bp_vec_op(bp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b,
+              const uint64_t s[4], size_t n, uint64_t* out);
+/* out[i] = prod_j (bit j of i ? ch[k-1-j] : ch_inv[k-1-j]), i < 2^k:
+ * src/ipa/mod.rs:134-148, HPoly::coeffs src/poly_commit/mod.rs:194-219.
+ * Swapping ch and ch_inv gives the inverse vector of src/ipa/mod.rs:150-154. */
+int bp_s_vector(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_inv, size_t k,
+                uint64_t* out);
+/* out[i] = x^i, i < n: powers_of_x src/poly_commit/mod.rs:16-22, y_vec
+ * src/range/aggregate.rs:88-91, hs' scalars src/range/utils.rs:22-29. */
+int bp_powers(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* out);
+/* In-place batch inverse, zeros stay zero: ark_ff::batch_inversion at
+ * src/ipa/mod.rs:130,152, src/poly_commit/mod.rs:197.  field: 0 = Fr, 1 = Fq. */
+int bp_batch_inverse(bp_ctx* ctx, int curve, int field, uint64_t* v, size_t n);
+
+/* ---- curve-vector kernels (host buffers) --------------------------------- */
+
+/* out[i] = x*L[i] + y*R[i], affine: fold_generators src/ipa/mod.rs:215-227,
+ * src/poly_commit/mod.rs:31-43.  x,y in Fr. */
+int bp_fold_generators(bp_ctx* ctx, int curve, const uint64_t* lx, const uint64_t* ly,
+                       const uint8_t* linf, const uint64_t* rx, const uint64_t* ry,
+                       const uint8_t* rinf, size_t h, const uint64_t x[4], const uint64_t y[4],
+                       uint64_t* out_x, uint64_t* out_y, uint8_t* out_inf);
+/* out[i] = s[i]*P[i], affine: the hs' construction h_i * y^-i at
+ * src/range/mod.rs:136-141,208-214, src/range/aggregate.rs:148-153,231-237,
+ * src/circuit/mod.rs:178-185,298-304. */
+int bp_scale_points(bp_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py,
+                    const uint8_t* pinf, const uint64_t* s, size_t n, uint64_t* out_x,
+                    uint64_t* out_y, uint8_t* out_inf);
+/* Jacobian (n*12 u64) -> affine: G::normalize_batch at src/ipa/mod.rs:187,226,
+ * src/range/aggregate.rs:223. */
+int bp_normalize_batch(bp_ctx* ctx, int curve, const uint64_t* xyz, size_t n, uint64_t* out_x,
+                       uint64_t* out_y, uint8_t* out_inf);
+
+/* ---- device-pointer forms of the streaming kernels ----------------------- */
+int bp_inner_product_dev(bp_ctx* ctx, int curve, const uint64_t* d_a, const uint64_t* d_b,
+                         size_t n, uint64_t out[4]);
+int bp_fold_scalars_dev(bp_ctx* ctx, int curve, const uint64_t* d_l, const uint64_t* d_r,
+                        size_t h, const uint64_t x[4], const uint64_t y[4], uint64_t* d_out);
+int bp_fold_generators_dev(bp_ctx* ctx, int curve, const uint64_t* d_lx, const uint64_t* d_ly,
+                           const uint8_t* d_linf, const uint64_t* d_rx, const uint64_t* d_ry,
+                           const uint8_t* d_rinf, size_t h, const uint64_t x[4],
+                           const uint64_t y[4], uint64_t* d_out_x, uint64_t* d_out_y,
+                           uint8_t* d_out_inf);
+int bp_s_vector_dev(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_inv, size_t k,
+                    uint64_t* d_out);
+
+/* ---- IPA round session ---------------------------------------------------- */
+
+/* Keeps G, H, a, b on the device across the `while n != 1` loop of ipa::prove
+ * (src/ipa/mod.rs:33-95) or poly_commit::prove (src/poly_commit/mod.rs:69-105;
+ * pass hs = NULL).  n must be a power of two >= 1.  The transcript stays with
+ * the caller: round_lr returns the MSM parts of L and R and the two cross
+ * inner products; the caller adds u*c (and h*l_j), derives the challenge and
+ * passes it (and its inverse) to round_fold. */
+int bp_ipa_begin(bp_ctx* ctx, int curve, int variant, const uint64_t* gx, const uint64_t* gy,
+                 const uint8_t* ginf, const uint64_t* hx, const uint64_t* hy, const uint8_t* hinf,
+                 const uint64_t* a, const uint64_t* b, size_t n, bp_ipa** out);
+int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t c_l[4],
+                    uint64_t c_r[4]);
+int bp_ipa_round_fold(bp_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]);
+size_t bp_ipa_len(const bp_ipa* s);
+/* Current vectors (length bp_ipa_len) copied to the host; any pointer may be NULL. */
+int bp_ipa_read(bp_ipa* s, uint64_t* gx, uint64_t* gy, uint8_t* ginf, uint64_t* hx, uint64_t* hy,
+                uint8_t* hinf, uint64_t* a, uint64_t* b);
+void bp_ipa_free(bp_ipa* s);
+
+/* ---- measurement helpers --------------------------------------------------- */
+
+/* Issues `iters` rounds of 64 independent 32x32+64 multiply-accumulates per lane
+ * on every CU and returns the measured rate in MAC/s: the denominator of the
+ * integer roofline. */
+int bp_bench_int_mad_peak(bp_ctx* ctx, int iters, double* mac_per_s);
+/* Duration in ms of the most recent launch of the named kernel group on this
+ * context, measured with HIP events on the context's stream.
+ * groups: 0 = MSM bucket accumulation, 1 = whole MSM device phase, 2 = last
+ * streaming kernel (fold/dot/s-vector). */
+int bp_last_kernel_ms(bp_ctx* ctx, int group, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BP_GPU_H */
