@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MSM throughput (points/s) at 2^20 secp256k1 points per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step is one multi-scalar multiplication over synthetic random points/scalars
+that are already resident in HBM when the timed region starts; the result is
+brought back to the host (it is what G::msm_unchecked returns).  At N > 1 every
+rank owns a 2^20-point shard of one N*2^20-point MSM (weak scaling): it computes
+the per-window partial sums of its shard, the partials are all-gathered over
+RCCL, and every rank combines them on its GPU.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (bucket
+accumulation) against the measured v_mad_u64_u32 issue rate; `cpu_baseline` is
+the C oracle's Pippenger timed on the host cores over a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG2_N = 20
+SEED = 0xB0117E7 + 2  # config index 2 of BASELINE.json ("Standalone MSM 2^16..2^20")
+MADD_MULS = 10        # XYZZ mixed addition: 8M + 2S
+MAC_PER_MUL = 136     # 8-limb Montgomery multiply: 2*8*8 + 8 32x32 multiply-accumulates
+
+
+def make_inputs(n, rank):
+    """P_i = (r0 + i*q) G by repeated addition on the device-independent generator
+    in the product library's own scale kernel is not needed here: values do not
+    change the work, so a small table of valid points is tiled; scalars are
+    uniform below 2^255 (below the group order)."""
+    import bulletproofs_amd as bp  # noqa: F401  (fails loudly if the library is missing)
+
+    rng = np.random.default_rng(SEED + 1000 * rank)
+    ks = rng.integers(0, 1 << 64, (n, 4), dtype=np.uint64)
+    ks[:, 3] &= np.uint64((1 << 63) - 1)
+    return ks
+
+
+def gen_points_on_gpu(ctx, n, rank):
+    """n distinct valid points: (rank*n + i + 1) * G computed by the library's own
+    per-point scaling kernel from the generator (setup, untimed)."""
+    # secp256k1 generator in Montgomery form
+    p = (1 << 256) - (1 << 32) - 977
+    gx = 0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798
+    gy = 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8
+    r = 1 << 256
+
+    def limbs(v):
+        return [(v >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]
+
+    order = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    X = np.tile(np.array(limbs(gx * r % p), dtype=np.uint64), (n, 1))
+    Y = np.tile(np.array(limbs(gy * r % p), dtype=np.uint64), (n, 1))
+    # scalars rank*n + i + 1 in Montgomery form: (v * R) mod order, vectorised via Python ints per chunk
+    base = rank * n + 1
+    rm = r % order
+    S = np.zeros((n, 4), dtype=np.uint64)
+    vals = [((base + i) * rm) % order for i in range(n)]
+    for k in range(4):
+        S[:, k] = np.array([(v >> (64 * k)) & ((1 << 64) - 1) for v in vals], dtype=np.uint64)
+    ox, oy, oi = ctx.scale_points(0, (X, Y, None), S)
+    assert not oi.any()
+    return ox, oy
+
+
+def cpu_baseline(n_sample):
+    """C oracle (oracle/bp_oracle.c, a port of the bucket method) on all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+
+    co = c_oracle.COracle()
+    # the GPU box exposes the whole machine's CPUs; its share is OMP_NUM_THREADS (16 there)
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    cores = max(1, min(cores, co.max_threads()))
+    rng = np.random.default_rng(SEED)
+    ks = rng.integers(0, 1 << 64, (n_sample, 4), dtype=np.uint64)
+    ks[:, 3] &= np.uint64((1 << 63) - 1)
+    # valid points: a tiled table of 4096 multiples of G from the oracle's own generator
+    p = (1 << 256) - (1 << 32) - 977
+    gx = 0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798
+    gy = 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8
+    r = 1 << 256
+    lim = lambda v: np.array([(v >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)  # noqa: E731
+    gxy = np.concatenate([lim(gx * r % p), lim(gy * r % p)])
+    px, py = co.gen_points(0, gxy, gxy, n_sample)
+    t0 = time.perf_counter()
+    co.msm(0, (px, py, None), ks, cores)
+    dt = time.perf_counter() - t0
+    return dict(value=n_sample / dt, unit="points/s", cores=cores, kind="port",
+                sample=f"one 2^{n_sample.bit_length() - 1}-point secp256k1 MSM, C restatement of the bucket method "
+                       f"(oracle/bp_oracle.c, OpenMP over windows), {dt:.2f} s; not the arkworks binary")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=LOG2_N)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import bulletproofs_amd as bp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = 1 << args.log2n
+    ctx = bp.Context(local_rank)
+    px, py = gen_points_on_gpu(ctx, n, rank)
+    ks = make_inputs(n, rank)
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()  # noqa: E731
+    dx, dy, dk = to_dev(px), to_dev(py), to_dev(ks)
+    win = torch.zeros(64 * 16, dtype=torch.int64, device="cuda")
+    gathered = torch.zeros((world, 64 * 16), dtype=torch.int64, device="cuda") if world > 1 else None
+
+    def step():
+        if world == 1:
+            return ctx.msm_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n)
+        nw, cb = ctx.msm_windows_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n, win.data_ptr())
+        dist.all_gather_into_tensor(gathered.view(-1), win)
+        torch.cuda.current_stream().synchronize()
+        packed = gathered[:, :nw * 16].contiguous()
+        return ctx.msm_combine_windows_dev(bp.SECP256K1, packed.data_ptr(), world, nw, cb)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    acc_ms, dev_ms = [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        acc_ms.append(ctx.last_kernel_ms(0))
+        dev_ms.append(ctx.last_kernel_ms(1))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        # plan facts: window width and count chosen by the library for this n
+        nw, cb = ctx.msm_windows_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n, win.data_ptr())
+        peak = ctx.int_mad_peak(4000)
+        acc_avg_s = float(np.mean(acc_ms)) * 1e-3
+        macs_per_launch = float(n) * nw * MADD_MULS * MAC_PER_MUL
+        achieved = macs_per_launch / acc_avg_s
+        out = {
+            "metric": "MSM points/sec at 2^20",
+            "value": world * n * args.steps / elapsed,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (256-bit Montgomery integers)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"standalone secp256k1 MSM, 2^{args.log2n} points/GPU, uniform scalars, inputs resident in HBM",
+                "points_per_gpu": n,
+                "curve": "secp256k1",
+                "window_bits": cb,
+                "windows": nw,
+                "parallelism": "1 GPU" if world == 1 else f"{world} GPUs, point-range shards, all-gather of window sums",
+                "seed": hex(SEED),
+                "device_phase_ms": float(np.mean(dev_ms)),
+            },
+            "roofline": {
+                "bound": "valu-int32-mad (v_mad_u64_u32 issue rate; not HBM, not MFMA)",
+                "kernel": "k_chunk_sums (bucket accumulation)",
+                "achieved": achieved / 1e12,
+                "peak": peak / 1e12,
+                "unit": "TMAC/s",
+                "frac": achieved / peak,
+                "avg_launch_ms": acc_avg_s * 1e3,
+                "algorithmic_mac_per_point": nw * MADD_MULS * MAC_PER_MUL,
+                "traffic": None,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(1 << 17)
+        assert res is not None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

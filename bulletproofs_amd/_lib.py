@@ -17,6 +17,34 @@ if not os.path.exists(LIB_PATH):
         "(or __graft_entry__.build()); bulletproofs_amd has no CPU fallback"
     )
 
+
+
+def _load_hip_runtime():
+    """libbp_gpu.so leaves the HIP runtime unbound; exactly one copy may live in a
+    process.  PyTorch wheels bundle their own libamdhip64, so when torch is
+    importable that copy is used (torch tensors' device pointers and
+    torch.distributed then share the library's runtime); otherwise the system one.
+    BP_HIP_RUNTIME=/path/to/libamdhip64.so overrides."""
+    path = os.environ.get("BP_HIP_RUNTIME")
+    if not path:
+        try:
+            import torch  # noqa: F401
+
+            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                path = cand
+        except ImportError:
+            pass
+    if not path:
+        for cand in ("/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"):
+            if cand.startswith("/") and not os.path.exists(cand):
+                continue
+            path = cand
+            break
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+hip_runtime = _load_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 u64p = C.POINTER(C.c_uint64)
@@ -66,6 +94,7 @@ SIGNATURES = {
     "bp_ipa_read": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "bp_ipa_free": (None, [vp]),
     "bp_bench_int_mad_peak": (ci, [vp, ci, C.POINTER(C.c_double)]),
+    "bp_microbench": (ci, [vp, ci, ci, ci, C.POINTER(C.c_float)]),
     "bp_last_kernel_ms": (ci, [vp, ci, C.POINTER(C.c_float)]),
 }
 

@@ -19,7 +19,7 @@ enum Slot {
   S_IN0, S_IN1, S_IN2, S_IN3, S_IN4, S_IN5, S_IN6,
   S_OUT0, S_OUT1, S_OUT2,
   S_KEYS_A, S_KEYS_B, S_VALS_A, S_VALS_B, S_SORT_TMP, S_BSTART, S_BEND, S_BUCKETS, S_SEGS,
-  S_WINDOWS, S_TABLE, S_SMALL, S_COUNT
+  S_WINDOWS, S_TABLE, S_SMALL, S_NCH, S_CHOFF, S_SCAN_TMP, S_CHUNK_SUMS, S_HEAVY, S_COUNT
 };
 
 struct DevBuf {
@@ -164,7 +164,7 @@ void finish_windows(int curve, const uint64_t* win, int n_windows, int c, uint64
 int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, MsmPlan* plan,
                u32** d_windows) {
   size_t n = p0.n + p1.n;
-  hipError_t e = msm_make_plan(n, ctx->c_override, plan);
+  hipError_t e = msm_make_plan(curve, n, ctx->c_override, plan);
   if (e != hipSuccess) return fail(ctx, BP_E_ARG, "msm plan (n too large?)", e);
   MsmWorkspace ws{};
   void* p;
@@ -176,6 +176,11 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
   CHK(reserve(ctx, S_BSTART, plan->bounds_bytes, &p)); ws.bucket_start = (u32*)p;
   CHK(reserve(ctx, S_BEND, plan->bounds_bytes, &p)); ws.bucket_end = (u32*)p;
   CHK(reserve(ctx, S_BUCKETS, plan->bucket_bytes, &p)); ws.buckets = (u32*)p;
+  CHK(reserve(ctx, S_NCH, plan->nch_bytes, &p)); ws.nch = (u32*)p;
+  CHK(reserve(ctx, S_CHOFF, plan->nch_bytes, &p)); ws.choff = (u32*)p;
+  CHK(reserve(ctx, S_SCAN_TMP, plan->scan_tmp_bytes, &p)); ws.scan_tmp = p;
+  CHK(reserve(ctx, S_CHUNK_SUMS, plan->chunk_sum_bytes, &p)); ws.chunk_sums = (u32*)p;
+  CHK(reserve(ctx, S_HEAVY, plan->nch_bytes + 256, &p)); ws.heavy = (u32*)p + 64; ws.heavy_count = (u32*)p;
   CHK(reserve(ctx, S_SEGS, plan->seg_bytes, &p)); ws.segs = (u32*)p;
   CHK(reserve(ctx, S_WINDOWS, plan->win_bytes, &p)); ws.windows = (u32*)p;
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
@@ -831,8 +836,32 @@ int bp_bench_int_mad_peak(bp_ctx* ctx, int iters, double* mac_per_s) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0;
   HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
-  double macs = (double)blocks * 256.0 * (double)iters * 64.0;
+  double macs = (double)blocks * 256.0 * (double)iters * 256.0;
   *mac_per_s = macs / ((double)ms * 1e-3);
+  return BP_OK;
+}
+
+int bp_microbench(bp_ctx* ctx, int id, int blocks, int iters, float* ms) {
+  if (!ctx || !ms || blocks < 1 || iters < 1) return fail(ctx, BP_E_ARG, "bp_microbench: bad argument");
+  Guard g(ctx);
+  void* io;
+  CHK(reserve(ctx, S_TABLE, 1024 * 32, &io));
+  std::vector<uint32_t> seed(1024 * 8);
+  uint64_t s = 0x9E3779B97F4A7C15ull;
+  for (auto& v : seed) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    v = (uint32_t)(s >> 33);
+  }
+  for (size_t i = 7; i < seed.size(); i += 8) seed[i] &= 0x3fffffffu;  // below every modulus
+  HIPCHK(ctx, hipMemcpyAsync(io, seed.data(), seed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipError_t e = launch_microbench(id, blocks, iters, (u32*)io, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_ARG, "bp_microbench: bad id", e);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  e = launch_microbench(id, blocks, iters, (u32*)io, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "bp_microbench", e);
+  HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev[4], ctx->ev[5]));
   return BP_OK;
 }
 

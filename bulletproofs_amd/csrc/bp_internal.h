@@ -37,6 +37,9 @@ size_t powers_table_elems(size_t n);
 hipError_t launch_batch_inverse(int curve, int field, u32* v, size_t n, hipStream_t st);
 hipError_t launch_int_mad_peak(int iters, u32* sink, int blocks, hipStream_t st);
 
+// io: 1024*8 u32 of seed data; ids: 0 fe_mul pair, 1 add+sub pair, 2 xyzz_madd, 3 jac_dbl, 4 fe_mul (Vesta Fq)
+hipError_t launch_microbench(int id, int blocks, int iters, u32* io, hipStream_t st);
+
 // ---- curve-vector kernels (bp_curvevec.hip) ----
 // scalars are canonical (non-Montgomery) little-endian 256-bit integers here
 hipError_t launch_fold_generators(int curve, const u32* lx, const u32* ly, const uint8_t* linf,
@@ -67,12 +70,15 @@ struct MsmPlan {
   size_t entries; // W * n_total
   // workspace sizes in bytes
   size_t keys_bytes, sort_tmp_bytes, bounds_bytes, bucket_bytes, seg_bytes, win_bytes;
+  size_t scan_tmp_bytes, nch_bytes, chunk_sum_bytes;
+  u32 chunk;      // max sorted entries per accumulation chunk
+  size_t nc_cap;  // upper bound on the number of chunks
   int seg_len;    // buckets per reduction segment
   u32 n_segs;     // per window
 };
 
 int msm_choose_window(size_t n);
-hipError_t msm_make_plan(size_t n_total, int c_override, MsmPlan* plan);
+hipError_t msm_make_plan(int curve, size_t n_total, int c_override, MsmPlan* plan);
 
 struct MsmWorkspace {
   u32* keys_a;
@@ -82,6 +88,12 @@ struct MsmWorkspace {
   void* sort_tmp;
   u32* bucket_start;  // (W*NB + 2)
   u32* bucket_end;
+  u32* nch;           // chunks per bucket (W*NB + 1)
+  u32* choff;         // exclusive scan of nch
+  void* scan_tmp;
+  u32* chunk_sums;    // XYZZ SoA: 4 planes * nc_cap * 8 u32
+  u32* heavy;         // queue of buckets with many chunks (W*NB)
+  u32* heavy_count;
   u32* buckets;       // XYZZ SoA: 4 planes * (W*NB) * 8 u32
   u32* segs;          // XYZZ AoS: W * n_segs * 32 u32
   u32* windows;       // XYZZ AoS: W * 32 u32

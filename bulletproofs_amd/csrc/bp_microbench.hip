@@ -1,0 +1,66 @@
+// Micro-benchmarks of the arithmetic building blocks, exported for bench/profiling
+// scripts through bp_microbench() (not part of the product path).
+#include "bp_curve.h"
+#include "bp_internal.h"
+
+namespace bp {
+
+template <class F>
+__global__ __launch_bounds__(256) void k_mb_mul(int iters, u32* __restrict__ io) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fe x = fe_load(io + (t & 1023) * 8), y = fe_load(io + ((t + 1) & 1023) * 8);
+  for (int i = 0; i < iters; i++) {
+    x = fe_mul<F>(x, y);
+    y = fe_mul<F>(y, x);
+  }
+  if (x.v[0] == 0x12345 && y.v[3] == 0x54321) fe_store(io, x);
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_mb_addsub(int iters, u32* __restrict__ io) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fe x = fe_load(io + (t & 1023) * 8), y = fe_load(io + ((t + 1) & 1023) * 8);
+  for (int i = 0; i < iters; i++) {
+    x = fe_add<F>(x, y);
+    y = fe_sub<F>(y, x);
+  }
+  if (x.v[0] == 0x12345 && y.v[3] == 0x54321) fe_store(io, x);
+}
+
+template <class F>
+__global__ __launch_bounds__(128) void k_mb_madd(int iters, u32* __restrict__ io) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fe qx = fe_load(io + (t & 1023) * 8), qy = fe_load(io + ((t + 1) & 1023) * 8);
+  Xyzz acc = xyzz_from_affine<F>(qy, qx);
+  for (int i = 0; i < iters; i++) {
+    xyzz_madd<F>(acc, qx, qy);
+    qx.v[0] ^= acc.x.v[0] & 1;
+  }
+  if (acc.x.v[0] == 0x12345 && acc.y.v[3] == 0x54321) fe_store(io, acc.x);
+}
+
+template <class F>
+__global__ __launch_bounds__(128) void k_mb_jdbl(int iters, u32* __restrict__ io) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Jac a;
+  a.x = fe_load(io + (t & 1023) * 8);
+  a.y = fe_load(io + ((t + 1) & 1023) * 8);
+  a.z = fe_load(io + ((t + 2) & 1023) * 8);
+  for (int i = 0; i < iters; i++) a = jac_dbl<F>(a);
+  if (a.x.v[0] == 0x12345 && a.y.v[3] == 0x54321) fe_store(io, a.x);
+}
+
+hipError_t launch_microbench(int id, int blocks, int iters, u32* io, hipStream_t st) {
+  using F = Secp256k1Fq;
+  switch (id) {
+    case 0: hipLaunchKernelGGL(k_mb_mul<F>, dim3(blocks), dim3(256), 0, st, iters, io); break;
+    case 1: hipLaunchKernelGGL(k_mb_addsub<F>, dim3(blocks), dim3(256), 0, st, iters, io); break;
+    case 2: hipLaunchKernelGGL(k_mb_madd<F>, dim3(blocks), dim3(128), 0, st, iters, io); break;
+    case 3: hipLaunchKernelGGL(k_mb_jdbl<F>, dim3(blocks), dim3(128), 0, st, iters, io); break;
+    case 4: hipLaunchKernelGGL(k_mb_mul<VestaFq>, dim3(blocks), dim3(256), 0, st, iters, io); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace bp

@@ -56,11 +56,14 @@ static int key_bits_for(u32 max_key) {
   return b;
 }
 
-hipError_t msm_make_plan(size_t n_total, int c_override, MsmPlan* plan) {
+hipError_t msm_make_plan(int curve, size_t n_total, int c_override, MsmPlan* plan) {
   MsmPlan p{};
   p.c = (c_override >= 2 && c_override <= 20) ? c_override : msm_choose_window(n_total);
-  // enough windows for a 256-bit scalar plus the carry of the signed recoding
-  p.n_windows = (257 + p.c - 1) / p.c;
+  // k_digits maps a scalar k > r/2 to r - k (and negates the point), so digits
+  // come from a value below 2^255 (secp256k1) or 2^254 (Vesta); one more bit
+  // absorbs the carry of the signed recoding.
+  const int value_bits = curve == BP_VESTA ? 254 : 255;
+  p.n_windows = (value_bits + 1 + p.c - 1) / p.c;
   p.n_buckets = 1u << (p.c - 1);
   p.n_total = n_total;
   p.entries = (size_t)p.n_windows * n_total;
@@ -80,6 +83,17 @@ hipError_t msm_make_plan(size_t n_total, int c_override, MsmPlan* plan) {
       key_bits_for(max_key), 0, false);
   if (e != hipSuccess) return e;
   p.sort_tmp_bytes = (tmp + 255) & ~(size_t)255;
+  // chunk length: up to 32 entries, shorter when the problem is small so that
+  // there are still tens of thousands of lanes
+  size_t t = p.entries / 65536;
+  p.chunk = (u32)(t < 4 ? 4 : (t > 32 ? 32 : t));
+  p.nc_cap = p.entries / p.chunk + nbt + 1;
+  p.nch_bytes = ((nbt + 2) * sizeof(u32) + 255) & ~(size_t)255;
+  p.chunk_sum_bytes = p.nc_cap * 4 * 32;
+  tmp = 0;
+  e = rocprim::exclusive_scan(nullptr, tmp, (u32*)nullptr, (u32*)nullptr, 0u, nbt + 1, rocprim::plus<u32>(), 0, false);
+  if (e != hipSuccess) return e;
+  p.scan_tmp_bytes = (tmp + 255) & ~(size_t)255;
   *plan = p;
   return hipSuccess;
 }
@@ -98,6 +112,23 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
   const u32* sp = i < n0 ? s0 + i * 8 : s1 + (i - n0) * 8;
   bool is_inf = i < n0 ? (inf0 && inf0[i]) : (inf1 && inf1[i - n0]);
   Fe k = fe_from_mont<Fr>(fe_load(sp));
+  // |k| <= r/2: use r - k with the point negated when that is the smaller value
+  u32 flip = 0;
+  {
+    Fe nk = fe_neg<Fr>(k);
+    bool gt = false, decided = false;
+#pragma unroll
+    for (int t = 7; t >= 0; t--) {
+      if (!decided && k.v[t] != nk.v[t]) {
+        gt = k.v[t] > nk.v[t];
+        decided = true;
+      }
+    }
+    if (gt) {
+      k = nk;
+      flip = 0x80000000u;
+    }
+  }
   const u32 invalid = (u32)n_windows * n_buckets;
   const u32 half = 1u << (c - 1);
   const u32 mask = (1u << c) - 1;
@@ -123,11 +154,11 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
       carry = 1;
       u32 mag = (1u << c) - v;  // |v - 2^c|
       key = mag ? (u32)w * n_buckets + (mag - 1) : invalid;  // v == 2^c: digit 0, carry 1
-      val = (u32)i | 0x80000000u;
+      val = ((u32)i | 0x80000000u) ^ flip;
     } else {
       carry = 0;
       key = v ? (u32)w * n_buckets + (v - 1) : invalid;
-      val = (u32)i;
+      val = (u32)i ^ flip;
     }
     if (is_inf) key = invalid;
     keys[(size_t)w * n + i] = key;
@@ -175,18 +206,43 @@ BP_DEV Xyzz xyzz_load_aos(const u32* p32) {
   return p;
 }
 
+// Work is cut into chunks of at most `chunk` sorted entries that never cross a
+// bucket boundary, so a bucket of any size (the top window's buckets are denser;
+// degenerate scalar sets put every point in one bucket) costs every lane at most
+// `chunk` additions.  nch[b] = chunks of bucket b; choff = its exclusive scan.
+__global__ __launch_bounds__(256) void k_chunk_counts(const u32* __restrict__ start,
+                                                      const u32* __restrict__ end, size_t nbt, u32 chunk,
+                                                      u32* __restrict__ nch) {
+  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nbt) return;
+  nch[b] = b < nbt ? (end[b] - start[b] + chunk - 1) / chunk : 0;
+}
+
 template <class C>
-__global__ __launch_bounds__(128) void k_accumulate(const u32* __restrict__ x0, const u32* __restrict__ y0,
+__global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ x0, const u32* __restrict__ y0,
                                                     size_t n0, const u32* __restrict__ x1,
                                                     const u32* __restrict__ y1,
                                                     const u32* __restrict__ vals,
                                                     const u32* __restrict__ start,
-                                                    const u32* __restrict__ end, size_t nbt,
-                                                    u32* __restrict__ buckets) {
+                                                    const u32* __restrict__ end,
+                                                    const u32* __restrict__ choff, size_t nbt, u32 chunk,
+                                                    size_t nc_cap, u32* __restrict__ buckets,
+                                                    u32* __restrict__ chunk_sums) {
   using F = typename C::Fq;
-  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nbt) return;
-  u32 s = start[b], e = end[b];
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  u32 nc = choff[nbt];
+  if (t >= nc) return;
+  // last bucket b with choff[b] <= t
+  size_t lo = 0, hi = nbt;  // invariant: choff[lo] <= t < choff[hi]
+  while (hi - lo > 1) {
+    size_t mid = (lo + hi) >> 1;
+    if (choff[mid] <= (u32)t) lo = mid; else hi = mid;
+  }
+  size_t b = lo;
+  u32 k = (u32)t - choff[b];
+  u32 s = start[b] + k * chunk, e = end[b];
+  bool single = (e - start[b]) <= chunk;
+  if (e - s > chunk) e = s + chunk;
   Xyzz acc = xyzz_identity<F>();
   for (u32 p = s; p < e; p++) {
     u32 v = vals[p];
@@ -198,7 +254,73 @@ __global__ __launch_bounds__(128) void k_accumulate(const u32* __restrict__ x0, 
     if (v >> 31) qy = fe_neg<F>(qy);
     xyzz_madd<F>(acc, qx, qy);
   }
+  if (single)
+    xyzz_store_soa(buckets, nbt, b, acc);
+  else
+    xyzz_store_soa(chunk_sums, nc_cap, t, acc);
+}
+
+// Buckets with 0 chunks become the identity, with 2..kFinishSerial chunks are
+// summed by one lane, with more are queued for k_bucket_heavy.
+constexpr u32 kFinishSerial = 8;
+
+template <class C>
+__global__ __launch_bounds__(128) void k_bucket_finish(const u32* __restrict__ nch,
+                                                       const u32* __restrict__ choff, size_t nbt,
+                                                       size_t nc_cap, const u32* __restrict__ chunk_sums,
+                                                       u32* __restrict__ buckets, u32* __restrict__ heavy,
+                                                       u32* __restrict__ heavy_count) {
+  using F = typename C::Fq;
+  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbt) return;
+  u32 n = nch[b];
+  if (n == 1) return;
+  if (n > kFinishSerial) {
+    u32 slot = atomicAdd(heavy_count, 1u);
+    heavy[slot] = (u32)b;
+    return;
+  }
+  Xyzz acc = xyzz_identity<F>();
+  u32 off = choff[b];
+  for (u32 k = 0; k < n; k++) {
+    Xyzz v = xyzz_load_soa(chunk_sums, nc_cap, off + k);
+    xyzz_add<F>(acc, v);
+  }
   xyzz_store_soa(buckets, nbt, b, acc);
+}
+
+// one block per queued bucket (grid-stride over the queue)
+template <class C>
+__global__ __launch_bounds__(256) void k_bucket_heavy(const u32* __restrict__ nch,
+                                                      const u32* __restrict__ choff, size_t nbt,
+                                                      size_t nc_cap, const u32* __restrict__ chunk_sums,
+                                                      u32* __restrict__ buckets,
+                                                      const u32* __restrict__ heavy,
+                                                      const u32* __restrict__ heavy_count) {
+  using F = typename C::Fq;
+  __shared__ u32 lds[256 * 32];
+  u32 count = *heavy_count;
+  for (u32 q = blockIdx.x; q < count; q += gridDim.x) {
+    u32 b = heavy[q];
+    u32 n = nch[b], off = choff[b];
+    Xyzz acc = xyzz_identity<F>();
+    for (u32 k = threadIdx.x; k < n; k += blockDim.x) {
+      Xyzz v = xyzz_load_soa(chunk_sums, nc_cap, off + k);
+      xyzz_add<F>(acc, v);
+    }
+    xyzz_store_aos(lds + threadIdx.x * 32, acc);
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        Xyzz v = xyzz_load_aos(lds + (threadIdx.x + o) * 32);
+        xyzz_add<F>(acc, v);
+        xyzz_store_aos(lds + threadIdx.x * 32, acc);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) xyzz_store_soa(buckets, nbt, b, acc);
+    __syncthreads();
+  }
 }
 
 // ---- 5. bucket reduction ----------------------------------------------------------
@@ -302,12 +424,27 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPla
   hipLaunchKernelGGL(k_bounds, dim3((unsigned)((plan.entries + 255) / 256)), dim3(256), 0, st, ws.keys_b,
                      plan.entries, ws.bucket_start, ws.bucket_end);
   if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_chunk_counts, dim3((unsigned)((nbt + 256) / 256)), dim3(256), 0, st, ws.bucket_start,
+                     ws.bucket_end, nbt, plan.chunk, ws.nch);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  tmp = plan.scan_tmp_bytes;
+  e = rocprim::exclusive_scan(ws.scan_tmp, tmp, ws.nch, ws.choff, 0u, nbt + 1, rocprim::plus<u32>(), st, false);
+  if (e != hipSuccess) return e;
+  if ((e = hipMemsetAsync(ws.heavy_count, 0, sizeof(u32), st)) != hipSuccess) return e;
   if (ev_acc0 && (e = hipEventRecord(ev_acc0, st)) != hipSuccess) return e;
-  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)((nbt + 127) / 128)), dim3(128),
-                                           0, st, p0.x, p0.y, p0.n, p1.x, p1.y, ws.vals_b,
-                                           ws.bucket_start, ws.bucket_end, nbt, ws.buckets));
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_chunk_sums<C>, dim3((unsigned)((plan.nc_cap + 127) / 128)), dim3(128),
+                                           0, st, p0.x, p0.y, p0.n, p1.x, p1.y, ws.vals_b, ws.bucket_start,
+                                           ws.bucket_end, ws.choff, nbt, plan.chunk, plan.nc_cap, ws.buckets,
+                                           ws.chunk_sums));
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;
+  DISPATCH_CURVE(curve, {
+    hipLaunchKernelGGL(k_bucket_finish<C>, dim3((unsigned)((nbt + 127) / 128)), dim3(128), 0, st, ws.nch, ws.choff,
+                       nbt, plan.nc_cap, ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
+    hipLaunchKernelGGL(k_bucket_heavy<C>, dim3(256), dim3(256), 0, st, ws.nch, ws.choff, nbt, plan.nc_cap,
+                       ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
+  });
+  if ((e = hipGetLastError()) != hipSuccess) return e;
   size_t nseg_threads = (size_t)plan.n_windows * plan.n_segs;
   DISPATCH_CURVE(curve, {
     hipLaunchKernelGGL(k_reduce_segments<C>, dim3((unsigned)((nseg_threads + 127) / 128)), dim3(128), 0, st,

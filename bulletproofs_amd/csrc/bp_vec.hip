@@ -331,24 +331,25 @@ hipError_t launch_batch_inverse(int curve, int field, u32* v, size_t n, hipStrea
 }
 
 // ---- integer multiply-accumulate peak probe -----------------------------------
-// 16 independent 32x32+64 accumulators per lane, 4 MACs each per iteration.
+// 32 independent 64-bit accumulators per lane, 8 v_mad_u64_u32 each per loop
+// iteration (256 per iteration), nothing else in the loop but its counter: the
+// instruction's issue rate with every CU busy.
 __global__ __launch_bounds__(256) void k_int_mad_peak(int iters, u32* __restrict__ sink) {
-  unsigned long long acc[16];
+  unsigned long long acc[32];
   u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 977u;
 #pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = (unsigned long long)i * 0x9E3779B97F4A7C15ull + a;
+  for (int i = 0; i < 32; i++) acc[i] = (unsigned long long)i * 0x9E3779B97F4A7C15ull + a;
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 8; r++) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) acc[i] = (unsigned long long)(a + i) * (u32)(b + r) + acc[i];
+      for (int i = 0; i < 32; i++)
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "vcc");
     }
-    a += (u32)acc[0];
-    b ^= (u32)(acc[1] >> 32);
   }
   unsigned long long x = 0;
 #pragma unroll
-  for (int i = 0; i < 16; i++) x ^= acc[i];
+  for (int i = 0; i < 32; i++) x ^= acc[i];
   if (x == 0x123456789abcdefull) sink[0] = (u32)x;  // keeps the chain live, practically never taken
 }
 

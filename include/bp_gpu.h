@@ -198,10 +198,15 @@ void bp_ipa_free(bp_ipa* s);
 
 /* ---- measurement helpers --------------------------------------------------- */
 
-/* Issues `iters` rounds of 64 independent 32x32+64 multiply-accumulates per lane
+/* Issues `iters` rounds of 256 independent 32x32+64 multiply-accumulates per lane
  * on every CU and returns the measured rate in MAC/s: the denominator of the
  * integer roofline. */
 int bp_bench_int_mad_peak(bp_ctx* ctx, int iters, double* mac_per_s);
+/* Times one launch (after a warm-up launch) of an arithmetic micro-benchmark:
+ * id 0 = 2*iters dependent Fq multiplies per lane (secp256k1), 1 = iters add+sub
+ * pairs, 2 = iters XYZZ mixed additions, 3 = iters Jacobian doublings, 4 = as 0 on
+ * Vesta's Fq.  256 (ids 0,1,4) or 128 lanes per block. */
+int bp_microbench(bp_ctx* ctx, int id, int blocks, int iters, float* ms);
 /* Duration in ms of the most recent launch of the named kernel group on this
  * context, measured with HIP events on the context's stream.
  * groups: 0 = MSM bucket accumulation, 1 = whole MSM device phase, 2 = last

@@ -1,0 +1,424 @@
+"""GPU parity tests: every entry point of the C ABI against the committed golden
+vectors and the CPU oracles on the same seeded inputs.  Integer work: bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bp_oracle as o
+from conftest import load_golden
+from gen_golden import ipa_inputs, msm_case_inputs
+from util import digest, pt_from_json, xyz_to_affine
+
+pytestmark = pytest.mark.gpu
+CURVES = [o.SECP256K1, o.VESTA]
+ids = lambda c: c.name  # noqa: E731
+
+
+def _curve(name):
+    return o.CURVES[name]
+
+
+def _dev(arr):
+    import torch
+
+    a = np.ascontiguousarray(arr)
+    if a.dtype == np.uint64:
+        a = a.view(np.int64)
+    return torch.from_numpy(a.copy()).cuda()
+
+
+def seeded_points(coracle, c, n, r0=777, q=31337):
+    """P_i = (r0 + i*q) G, generated with the C oracle (fast for large n)."""
+    st, sp = o.scalar_mul(r0, c.g, c), o.scalar_mul(q, c.g, c)
+    sxy = np.concatenate([o.pack_field([st[0]], c.p)[0], o.pack_field([st[1]], c.p)[0]])
+    pxy = np.concatenate([o.pack_field([sp[0]], c.p)[0], o.pack_field([sp[1]], c.p)[0]])
+    return coracle.gen_points(c.id, sxy, pxy, n)
+
+
+def random_scalars(c, n, seed):
+    """uniform canonical scalars below the modulus as Montgomery limbs (numpy path for large n)"""
+    rng = np.random.default_rng(seed)
+    raw = rng.integers(0, 1 << 64, (n, 4), dtype=np.uint64)
+    raw[:, 3] &= np.uint64((1 << (62 if c.id else 63)) - 1)  # below both moduli
+    ints = [o.limbs_to_int(r) for r in raw]
+    return ints, o.pack_field(ints, c.n)
+
+
+# ---- field vectors ---------------------------------------------------------------
+
+
+def test_vector_kernels_golden(ctx):
+    for fx in load_golden("vectors"):
+        c = _curve(fx["curve"])
+        rng = o.SplitMix64(fx["seed"])
+        n = fx["n"]
+        a, b = rng.scalars(n, c.n), rng.scalars(n, c.n)
+        x, y = rng.field(c.n), rng.field(c.n)
+        A, B, X, Y = (o.pack_field(v, c.n) for v in (a, b, [x], [y]))
+        assert hex(o.unpack_field(ctx.inner_product(c.id, A, B), c.n)[0]) == fx["inner_product"]
+        assert hex(o.unpack_field(ctx.sum(c.id, A), c.n)[0]) == fx["sum"]
+        assert digest(o.unpack_field(ctx.fold_scalars(c.id, A, B, X, Y), c.n)) == fx["fold_scalars_sha256"]
+        assert digest(o.unpack_field(ctx.hadamard(c.id, A, B), c.n)) == fx["hadamard_sha256"]
+        assert digest(o.unpack_field(ctx.vector_add(c.id, A, B), c.n)) == fx["add_sha256"]
+        assert digest(o.unpack_field(ctx.vector_sub(c.id, A, B), c.n)) == fx["sub_sha256"]
+        assert digest(o.unpack_field(ctx.scale(c.id, A, X), c.n)) == fx["scale_sha256"]
+        assert digest(o.unpack_field(ctx.powers(c.id, X, 777), c.n)) == fx["powers_sha256"]
+        assert digest(o.unpack_field(ctx.batch_inversion(c.id, A), c.n)) == fx["batch_inverse_sha256"]
+        axpy = o.unpack_field(ctx.axpy(c.id, A, X, B), c.n)
+        assert axpy == [(u + x * v) % c.n for u, v in zip(a, b)]
+        for k, blk in fx["s_vector"].items():
+            k = int(k)
+            ch = o.SplitMix64(fx["seed"] + 1000 + k).scalars(k, c.n)
+            chi = [pow(v, -1, c.n) for v in ch]
+            s = o.unpack_field(ctx.s_vector(c.id, o.pack_field(ch, c.n), o.pack_field(chi, c.n)), c.n)
+            assert digest(s) == blk["sha256"] and [hex(v) for v in s[:4]] == blk["first"]
+        # HPoly::evaluate == <coeffs, powers>  (src/poly_commit/mod.rs:324-346)
+        xe = int(fx["hpoly_eval"]["x"], 16)
+        ch5 = o.SplitMix64(fx["seed"] + 1005).scalars(5, c.n)
+        ss = ctx.s_vector(c.id, o.pack_field(ch5, c.n), o.pack_field([pow(v, -1, c.n) for v in ch5], c.n))
+        pw = ctx.powers(c.id, o.pack_field([xe], c.n), 32)
+        assert hex(o.unpack_field(ctx.inner_product(c.id, ss, pw), c.n)[0]) == fx["hpoly_eval"]["value"]
+
+
+def test_vector_ops_reference_literals(ctx):
+    """src/vector_ops.rs:238-314 through the GPU path."""
+    c = o.SECP256K1
+    f = lambda v: o.pack_field(v, c.n)  # noqa: E731
+    assert o.unpack_field(ctx.vector_add(c.id, f([1, 2, 3]), f([4, 5, 6])), c.n) == [5, 7, 9]
+    assert o.unpack_field(ctx.inner_product(c.id, f([1, 2, 3]), f([4, 5, 6])), c.n) == [32]
+    s = ctx.vector_add(c.id, f([1, 2, 3]), f([2, 3, 4]))
+    assert o.unpack_field(ctx.inner_product(c.id, s, ctx.scale(c.id, f([1, 1, 1]), f([5]))), c.n) == [75]
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_vector_edge_cases(ctx, c):
+    empty = np.zeros((0, 4), dtype=np.uint64)
+    assert o.unpack_field(ctx.inner_product(c.id, empty, empty), c.n) == [0]
+    assert o.unpack_field(ctx.sum(c.id, empty), c.n) == [0]
+    assert ctx.fold_scalars(c.id, empty, empty, o.pack_field([3], c.n), o.pack_field([4], c.n)).shape == (0, 4)
+    # ragged: zip to the shorter, as the reference's iterator adaptors do
+    a, b = [5, 6, 7, 8, 9], [1, 2, 3]
+    assert o.unpack_field(ctx.inner_product(c.id, o.pack_field(a, c.n), o.pack_field(b, c.n)), c.n) == [38]
+    # extremes
+    m = c.n - 1
+    A = o.pack_field([m, m, 0, 1], c.n)
+    assert o.unpack_field(ctx.hadamard(c.id, A, A), c.n) == [1, 1, 0, 1]
+    assert o.unpack_field(ctx.vector_add(c.id, A, A), c.n) == [c.n - 2, c.n - 2, 0, 2]
+    assert o.unpack_field(ctx.batch_inversion(c.id, A), c.n) == [m, m, 0, 1]
+    # k = 0 s-vector is [1]
+    assert o.unpack_field(ctx.s_vector(c.id, empty, empty), c.n) == [1]
+    # large dot against the C oracle is covered in test_large_vectors_vs_c_oracle
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_large_vectors_vs_c_oracle(ctx, coracle, c):
+    n = (1 << 17) + 13
+    _, A = random_scalars(c, n, 11)
+    _, B = random_scalars(c, n, 12)
+    X, Y = A[5:6].copy(), B[7:8].copy()
+    assert np.array_equal(ctx.inner_product(c.id, A, B), coracle.inner_product(c.id, A, B))
+    assert np.array_equal(ctx.sum(c.id, A), coracle.sum(c.id, A))
+    assert np.array_equal(ctx.fold_scalars(c.id, A, B, X, Y), coracle.fold_scalars(c.id, A, B, X, Y, 8))
+    ch, chi = A[:15].copy(), ctx.batch_inversion(c.id, A[:15])
+    assert np.array_equal(ctx.s_vector(c.id, ch, chi), coracle.s_vector(c.id, ch, chi, 8))
+    fq = ctx.batch_inversion(c.id, A[:1000], field=1)  # base-field inversion
+    vals = o.unpack_field(A[:1000], c.p) if c.id else None
+    if vals is not None:  # Vesta: every 254-bit value is below p as well
+        assert o.unpack_field(fq, c.p) == o.batch_inversion(vals, c.p)
+
+
+# ---- MSM ----------------------------------------------------------------------------
+
+
+def test_msm_golden(ctx):
+    for fx in load_golden("msm"):
+        c = _curve(fx["curve"])
+        if fx["case"] == "closed_form":
+            rng = o.SplitMix64(fx["seed"])
+            r0, q = rng.field(c.n), rng.field(c.n)
+            pts = o.gen_points_arith(fx["n"], r0, q, c)
+            ks = rng.scalars(fx["n"], c.n)
+        else:
+            pts, ks = msm_case_inputs(fx["case"], fx["n"], c, fx["seed"])
+        P, K = o.pack_points(pts, c), o.pack_field(ks, c.n)
+        got = xyz_to_affine(ctx.msm_unchecked(c.id, P, K), c)
+        assert got == pt_from_json(fx["expect"]), (fx["curve"], fx["case"], fx["n"])
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_msm_edge_shapes(ctx, c):
+    empty_f = np.zeros((0, 4), dtype=np.uint64)
+    assert xyz_to_affine(ctx.msm_unchecked(c.id, (empty_f, empty_f, None), empty_f), c) is None
+    pts = o.gen_points_arith(10, 5, 7, c)
+    ks = o.SplitMix64(3).scalars(10, c.n)
+    P, K = o.pack_points(pts, c), o.pack_field(ks, c.n)
+    # unequal lengths: msm_unchecked zips to the shorter slice
+    got = xyz_to_affine(ctx.msm_unchecked(c.id, P, K[:6]), c)
+    assert got == o.msm_naive(pts[:6], ks[:6], c)
+    # all bases the identity
+    inf = np.ones(10, dtype=np.uint8)
+    assert xyz_to_affine(ctx.msm_unchecked(c.id, (P[0], P[1], inf), K), c) is None
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_msm_window_sweep(ctx, coracle, c):
+    """every window width gives the same group element"""
+    n = 1500
+    px, py = seeded_points(coracle, c, n)
+    ints, K = random_scalars(c, n, 5)
+    exp = coracle.msm(c.id, (px, py, None), K, 8)
+    try:
+        for w in (2, 3, 5, 8, 11, 13, 16):
+            ctx.set_msm_window(w)
+            assert np.array_equal(ctx.msm_unchecked(c.id, (px, py, None), K), exp), w
+    finally:
+        ctx.set_msm_window(0)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_msm_degenerate_distributions(ctx, coracle, c):
+    """range-proof A-commitment scalars ({0,1,-1}: src/range/aggregate.rs:50-64) and a
+    single repeated scalar put every point of a window into one bucket"""
+    n = 8192
+    px, py = seeded_points(coracle, c, n, 99, 101)
+    rng = np.random.default_rng(8)
+    bits = rng.integers(0, 2, n // 2)
+    ks = [int(b) for b in bits] + [(int(b) - 1) % c.n for b in bits]
+    K = o.pack_field(ks, c.n)
+    assert np.array_equal(ctx.msm_unchecked(c.id, (px, py, None), K), coracle.msm(c.id, (px, py, None), K, 8))
+    K2 = np.repeat(o.pack_field([ks[-1] * 12345 % c.n], c.n), n, axis=0)
+    assert np.array_equal(ctx.msm_unchecked(c.id, (px, py, None), K2), coracle.msm(c.id, (px, py, None), K2, 8))
+
+
+@pytest.mark.parametrize("logn", [16, 18])
+def test_msm_large_closed_form(ctx, coracle, logn):
+    """sum k_i (r0 + i q) G has a closed form at any size"""
+    c = o.SECP256K1
+    n = 1 << logn
+    r0, q = 424242, 31337
+    px, py = seeded_points(coracle, c, n, r0, q)
+    ints, K = random_scalars(c, n, logn)
+    acc = 0
+    for i, k in enumerate(ints):
+        acc += k * (r0 + i * q)
+    exp = o.scalar_mul(acc % c.n, c.g, c)
+    assert xyz_to_affine(ctx.msm_unchecked(c.id, (px, py, None), K), c) == exp
+
+
+def test_msm_full_size_properties(ctx, coracle):
+    """BASELINE size (2^20): closed form + linearity, device-resident inputs"""
+    c = o.SECP256K1
+    n = 1 << 20
+    r0, q = 987654321, 1234577
+    px, py = seeded_points(coracle, c, n, r0, q)
+    ints1, K1 = random_scalars(c, n, 21)
+    ints2, K2 = random_scalars(c, n, 22)
+    dx, dy, d1, d2 = _dev(px), _dev(py), _dev(K1), _dev(K2)
+    r1 = xyz_to_affine(ctx.msm_dev(c.id, dx.data_ptr(), dy.data_ptr(), None, d1.data_ptr(), n), c)
+    r2 = xyz_to_affine(ctx.msm_dev(c.id, dx.data_ptr(), dy.data_ptr(), None, d2.data_ptr(), n), c)
+    w = np.arange(n, dtype=object) * q + r0
+    e1 = int(np.dot(np.array(ints1, dtype=object), w)) % c.n
+    e2 = int(np.dot(np.array(ints2, dtype=object), w)) % c.n
+    assert r1 == o.scalar_mul(e1, c.g, c) and r2 == o.scalar_mul(e2, c.g, c)
+    K3 = ctx.vector_add(c.id, K1, K2)
+    d3 = _dev(K3)
+    r3 = xyz_to_affine(ctx.msm_dev(c.id, dx.data_ptr(), dy.data_ptr(), None, d3.data_ptr(), n), c)
+    assert r3 == o.add(r1, r2, c)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_msm_resident_and_two_part(ctx, coracle, c):
+    n = 3000
+    px, py = seeded_points(coracle, c, n, 31, 17)
+    ints, K = random_scalars(c, n, 9)
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[5] = 1
+    bases = ctx.register_bases(c.id, (px, py, inf))
+    assert len(bases) == n
+    for off, cnt in ((0, n), (100, 1024), (2999, 1), (7, 0)):
+        exp = coracle.msm(c.id, (px[off:off + cnt], py[off:off + cnt], inf[off:off + cnt]), K[:cnt], 4)
+        assert np.array_equal(bases.msm(K[:cnt], off, cnt), exp), (off, cnt)
+    with pytest.raises(Exception):
+        bases.msm(K[:10], n - 5, 10)
+    bases.free()
+    # two-part form = concatenated form (src/ipa/mod.rs:44-54)
+    dx, dy, dk = _dev(px), _dev(py), _dev(K)
+    h = 1000
+    part0 = (dx.data_ptr() + 32 * h, dy.data_ptr() + 32 * h, None, dk.data_ptr(), h)
+    part1 = (dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr() + 32 * h, h)
+    exp = coracle.msm(c.id, (np.concatenate([px[h:2 * h], px[:h]]), np.concatenate([py[h:2 * h], py[:h]]), None),
+                      K[:2 * h], 4)
+    assert np.array_equal(ctx.msm2_dev(c.id, part0, part1), exp)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_msm_window_partials_combine(ctx, coracle, c):
+    """the multi-GPU path on one GPU: per-shard window sums, gathered and combined"""
+    import torch
+
+    n = 4096
+    px, py = seeded_points(coracle, c, n, 3, 5)
+    ints, K = random_scalars(c, n, 4)
+    dx, dy, dk = _dev(px), _dev(py), _dev(K)
+    parts = 4
+    m = n // parts
+    gathered = torch.zeros((parts, 64 * 16), dtype=torch.int64, device="cuda")
+    shape = None
+    for r in range(parts):
+        nw, cb = ctx.msm_windows_dev(c.id, dx.data_ptr() + 32 * m * r, dy.data_ptr() + 32 * m * r, None,
+                                     dk.data_ptr() + 32 * m * r, m, gathered[r].data_ptr())
+        assert shape in (None, (nw, cb))
+        shape = (nw, cb)
+    nw, cb = shape
+    packed = gathered[:, :nw * 16].contiguous()
+    got = ctx.msm_combine_windows_dev(c.id, packed.data_ptr(), parts, nw, cb)
+    assert np.array_equal(got, coracle.msm(c.id, (px, py, None), K, 8))
+
+
+# ---- curve vectors --------------------------------------------------------------------
+
+
+def test_curve_vectors_golden(ctx):
+    for fx in load_golden("vectors"):
+        c = _curve(fx["curve"])
+        rng = o.SplitMix64(fx["seed"])
+        n = fx["n"]
+        rng.scalars(n, c.n), rng.scalars(n, c.n)
+        x, y = rng.field(c.n), rng.field(c.n)
+        rng.field(c.n)
+        pts = o.gen_points_arith(24, rng.field(c.n), rng.field(c.n), c)
+        PX, PY, PI = o.pack_points(pts, c)
+        X, Y = o.pack_field([x], c.n), o.pack_field([y], c.n)
+        out = ctx.fold_generators(c.id, (PX[:12], PY[:12], PI[:12]), (PX[12:], PY[12:], PI[12:]), X, Y)
+        assert o.unpack_points(*out, c) == [pt_from_json(p) for p in fx["fold_generators"]]
+        ysc = o.pack_field(o.hs_prime_scalars(12, y, c.n), c.n)
+        assert np.array_equal(ysc, ctx.powers(c.id, o.pack_field([pow(y, -1, c.n)], c.n), 12))
+        out = ctx.scale_points(c.id, (PX[:12], PY[:12], PI[:12]), ysc)
+        assert o.unpack_points(*out, c) == [pt_from_json(p) for p in fx["hs_prime"]]
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_curve_vectors_edge_and_large(ctx, coracle, c):
+    n = 2048
+    px, py = seeded_points(coracle, c, n, 41, 43)
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[[0, 3, 1024 + 3, 1500]] = 1          # identity on the left, both sides, right only
+    px[1030], py[1030] = px[6], py[6]        # L == R: doubling inside L + R
+    py_neg = o.pack_field([(-v) % c.p for v in o.unpack_field(py[7:8], c.p)], c.p)
+    px[1031], py[1031] = px[7], py_neg[0]    # L == -R
+    ints, K = random_scalars(c, 4, 77)
+    X, Y = K[0:1], K[1:2]
+    L, R = (px[:1024], py[:1024], inf[:1024]), (px[1024:], py[1024:], inf[1024:])
+    got = ctx.fold_generators(c.id, L, R, X, Y)
+    exp = coracle.fold_generators(c.id, L, R, X, Y, 8)
+    assert all(np.array_equal(g, e) for g, e in zip(got, exp))
+    # x = y: both scalars equal; x = 0; y = 1
+    one, zero = o.pack_field([1], c.n), o.pack_field([0], c.n)
+    for xs, ys in ((X, X), (zero, one), (zero, zero)):
+        got = ctx.fold_generators(c.id, (px[:64], py[:64], inf[:64]), (px[1024:1088], py[1024:1088], inf[1024:1088]), xs, ys)
+        exp = coracle.fold_generators(c.id, (px[:64], py[:64], inf[:64]), (px[1024:1088], py[1024:1088], inf[1024:1088]), xs, ys, 8)
+        assert all(np.array_equal(g, e) for g, e in zip(got, exp))
+    _, S = random_scalars(c, 512, 78)
+    S[3] = 0
+    S[4] = o.pack_field([c.n - 1], c.n)[0]
+    got = ctx.scale_points(c.id, (px[:512], py[:512], inf[:512]), S)
+    exp = coracle.scale_points(c.id, (px[:512], py[:512], inf[:512]), S, 8)
+    assert all(np.array_equal(g, e) for g, e in zip(got, exp))
+    # normalize_batch: Jacobian (X*z^2, Y*z^3, z) -> the affine inputs
+    zs = o.SplitMix64(5).scalars(16, c.p)
+    xs, ys_ = o.unpack_field(px[:16], c.p), o.unpack_field(py[:16], c.p)
+    jac = np.zeros((16, 12), dtype=np.uint64)
+    for i in range(16):
+        z = zs[i] if i != 2 else 0
+        jac[i, 0:4] = o.pack_field([xs[i] * z * z], c.p)[0]
+        jac[i, 4:8] = o.pack_field([ys_[i] * z * z * z], c.p)[0]
+        jac[i, 8:12] = o.pack_field([z], c.p)[0]
+    ox, oy, oi = ctx.normalize_batch(c.id, jac)
+    assert oi[2] == 1 and oi.sum() == 1
+    keep = [i for i in range(16) if i != 2]
+    assert np.array_equal(ox[keep], px[:16][keep]) and np.array_equal(oy[keep], py[:16][keep])
+
+
+# ---- IPA sessions ------------------------------------------------------------------------
+
+
+def test_ipa_rounds_golden(ctx):
+    for fx in load_golden("ipa"):
+        c = _curve(fx["curve"])
+        n, variant = fx["n"], fx["variant"]
+        g, h, a, b, ch = ipa_inputs(c, n, fx["seed"])
+        s = ctx.ipa_begin(c.id, variant, o.pack_points(g, c), o.pack_points(h, c) if variant == 0 else None,
+                          o.pack_field(a, c.n), o.pack_field(b, c.n))
+        for r, x in zip(fx["rounds"], ch):
+            L, R, cl, cr = s.round_lr()
+            assert xyz_to_affine(L, c) == pt_from_json(r["L"]) and xyz_to_affine(R, c) == pt_from_json(r["R"])
+            assert hex(o.unpack_field(cl, c.n)[0]) == r["cL"] and hex(o.unpack_field(cr, c.n)[0]) == r["cR"]
+            s.round_fold(o.pack_field([x], c.n), o.pack_field([pow(x, -1, c.n)], c.n))
+        assert len(s) == 1
+        G, H, A, B = s.read()
+        assert o.unpack_points(*G, c) == [pt_from_json(fx["final"]["g"])]
+        assert [hex(v) for v in o.unpack_field(A, c.n)] == [fx["final"]["a"]]
+        assert [hex(v) for v in o.unpack_field(B, c.n)] == [fx["final"]["b"]]
+        if variant == 0:
+            assert o.unpack_points(*H, c) == [pt_from_json(fx["final"]["h"])]
+        with pytest.raises(Exception):
+            s.round_lr()  # already folded to length 1: BP_E_STATE
+        s.free()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_ipa_final_generator_property(ctx, coracle, variant):
+    """n = 2^11: the folded generator equals MSM(gs, s-vector) (src/poly_commit/mod.rs:108-113)
+    and every round's L/R match the C oracle's MSM of the same slices"""
+    c = o.SECP256K1
+    n, k = 1 << 11, 11
+    gx, gy = seeded_points(coracle, c, n, 7, 11)
+    hx, hy = seeded_points(coracle, c, n, 70001, 13)
+    _, A = random_scalars(c, n, 1)
+    _, B = random_scalars(c, n, 2)
+    _, CH = random_scalars(c, k, 3)
+    CHI = ctx.batch_inversion(c.id, CH)
+    s = ctx.ipa_begin(c.id, variant, (gx, gy, None), (hx, hy, None) if variant == 0 else None, A, B)
+    g_cur, h_cur, a_cur, b_cur = (gx, gy), (hx, hy), A, B
+    for j in range(k):
+        L, R, cl, cr = s.round_lr()
+        if j < 3:  # spot-check the first rounds against the C oracle on the host copies
+            (g2, h2, a_cur, b_cur) = s.read() if j else ((gx, gy, None), (hx, hy, None), A, B)
+            m = len(a_cur) // 2
+            if variant == 0:
+                bases = (np.concatenate([g2[0][m:], h2[0][:m]]), np.concatenate([g2[1][m:], h2[1][:m]]), None)
+                sc = np.concatenate([a_cur[:m], b_cur[m:]])
+            else:
+                bases, sc = (g2[0][m:], g2[1][m:], None), a_cur[:m]
+            assert np.array_equal(L, coracle.msm(c.id, bases, sc, 8))
+            assert np.array_equal(cl, coracle.inner_product(c.id, a_cur[:m], b_cur[m:]))
+            assert np.array_equal(cr, coracle.inner_product(c.id, a_cur[m:], b_cur[:m]))
+        s.round_fold(CH[j:j + 1], CHI[j:j + 1])
+    G, H, Af, Bf = s.read()
+    ss = ctx.s_vector(c.id, CH, CHI)
+    exp = ctx.msm_unchecked(c.id, (gx, gy, None), ss)
+    ex, ey, _ = ctx.normalize_batch(c.id, exp.reshape(1, 12))
+    assert np.array_equal(G[0], ex) and np.array_equal(G[1], ey)
+    assert np.array_equal(exp, coracle.msm(c.id, (gx, gy, None), ss, 8))
+    s.free()
+
+
+# ---- error behaviour -----------------------------------------------------------------------
+
+
+def test_error_codes(ctx):
+    from bulletproofs_amd import BpError
+
+    f = np.zeros((4, 4), dtype=np.uint64)
+    with pytest.raises(BpError) as e:
+        ctx.inner_product(7, f, f)
+    assert e.value.code == -2
+    with pytest.raises(BpError) as e:
+        ctx.ipa_begin(0, 0, (f[:3], f[:3], None), (f[:3], f[:3], None), f[:3], f[:3])  # n not a power of two
+    assert e.value.code == -1
+    with pytest.raises(BpError) as e:
+        ctx.ipa_begin(0, 0, (f, f, None), None, f, f)  # bulletproof variant needs hs
+    assert e.value.code == -1
+    with pytest.raises(BpError):
+        ctx.set_msm_window(1)
