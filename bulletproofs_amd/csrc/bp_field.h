@@ -73,73 +73,48 @@ BP_DEV Fe fe_select(bool c, const Fe& a, const Fe& b) {  // c ? a : b
   return r;
 }
 
-// r = a - p, returns borrow (1 when a < p)
-template <class F>
-BP_DEV uint32_t fe_sub_mod_raw(Fe& r, const Fe& a) {
-  int64_t c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (int64_t)a.v[i] - (int64_t)F::mod(i);
-    r.v[i] = (uint32_t)c;
-    c >>= 32;
-  }
-  return (uint32_t)(c & 1);
-}
+// Carry chains are written with __builtin_addc/__builtin_subc, which hipcc lowers
+// to v_add_co_u32 / v_addc_co_u32 (v_sub_co / v_subb_co) runs with the modulus
+// limbs as literals.
 
 // reduce a value known to be < 2p (carry = bit 256 of the value)
 template <class F>
 BP_DEV Fe fe_reduce_once(const Fe& a, uint32_t carry) {
   Fe d;
-  uint32_t borrow = fe_sub_mod_raw<F>(d, a);
-  bool use_d = F::kFullWidth ? (carry != 0 || borrow == 0) : (borrow == 0);
-  return fe_select(use_d, d, a);
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(a.v[i], F::mod(i), bw, &bw);
+  bool keep = F::kFullWidth ? (carry == 0 && bw != 0) : (bw != 0);
+  return fe_select(keep, a, d);
 }
 
 template <class F>
 BP_DEV Fe fe_add(const Fe& a, const Fe& b) {
   Fe s;
-  uint64_t c = 0;
+  uint32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (uint64_t)a.v[i] + b.v[i];
-    s.v[i] = (uint32_t)c;
-    c >>= 32;
-  }
-  return fe_reduce_once<F>(s, (uint32_t)c);
+  for (int i = 0; i < 8; i++) s.v[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
+  return fe_reduce_once<F>(s, c);
 }
 
 template <class F>
 BP_DEV Fe fe_sub(const Fe& a, const Fe& b) {
-  Fe d;
-  int64_t c = 0;
+  Fe d, r;
+  uint32_t bw = 0, c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (int64_t)a.v[i] - (int64_t)b.v[i];
-    d.v[i] = (uint32_t)c;
-    c >>= 32;
-  }
-  uint32_t mask = (uint32_t)c;  // 0 or 0xffffffff when a < b
-  uint64_t k = 0;
-  Fe r;
+  for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(a.v[i], b.v[i], bw, &bw);
+  uint32_t mask = 0u - bw;  // all ones when a < b
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    k += (uint64_t)d.v[i] + (F::mod(i) & mask);
-    r.v[i] = (uint32_t)k;
-    k >>= 32;
-  }
+  for (int i = 0; i < 8; i++) r.v[i] = __builtin_addc(d.v[i], F::mod(i) & mask, c, &c);
   return r;
 }
 
 template <class F>
 BP_DEV Fe fe_neg(const Fe& a) {
   Fe r;
-  int64_t c = 0;
+  uint32_t bw = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (int64_t)F::mod(i) - (int64_t)a.v[i];
-    r.v[i] = (uint32_t)c;
-    c >>= 32;
-  }
+  for (int i = 0; i < 8; i++) r.v[i] = __builtin_subc(F::mod(i), a.v[i], bw, &bw);
   return fe_select(fe_is_zero(a), a, r);
 }
 
@@ -153,10 +128,10 @@ BP_DEV Fe fe_dbl(const Fe& a) {
   return fe_reduce_once<F>(s, carry);
 }
 
-// Montgomery product a*b*2^-256 mod p.  CIOS, 8 outer steps; each step is a
-// row of 8 multiply-accumulates for a*b[i] and a row of 8 for m*p.
+// Montgomery product a*b*2^-256 mod p, portable form (host builds of this header
+// and the reference for the device form below).  CIOS, 8 outer steps.
 template <class F>
-BP_DEV Fe fe_mul(const Fe& a, const Fe& b) {
+BP_DEV Fe fe_mul_portable(const Fe& a, const Fe& b) {
   uint32_t t[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) t[i] = 0;
@@ -188,6 +163,93 @@ BP_DEV Fe fe_mul(const Fe& a, const Fe& b) {
   for (int i = 0; i < 8; i++) r.v[i] = t[i];
   return fe_reduce_once<F>(r, t[8]);
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device form: product scanning (column by column).  A column's partial products
+// are summed into a 96-bit accumulator {acc (64 bits), ovf (32 bits)}: each
+// product is one v_mad_u64_u32 whose 64-bit addend is the accumulator itself,
+// followed by one v_addc_co_u32 that counts the carry-out.  Two instructions per
+// 32x32 product, no register shuffling inside a column.
+BP_DEV void bp_mac(uint64_t& acc, uint32_t& ovf, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(ovf)
+      : "v"(a), "v"(b)
+      : "vcc");
+}
+// multiplier is a compile-time constant: SGPR operand, or the inline constant -1
+template <uint32_t K>
+BP_DEV void bp_mac_const(uint64_t& acc, uint32_t& ovf, uint32_t a) {
+  if constexpr (K == 0xffffffffu) {
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(ovf)
+        : "v"(a)
+        : "vcc");
+  } else if constexpr (K == 1u) {
+    asm("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(ovf)
+        : "v"(a)
+        : "vcc");
+  } else if constexpr (K != 0u) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(ovf)
+        : "v"(a), "s"(K)
+        : "vcc");
+  }
+}
+// next column: acc <- {acc.hi, ovf}, ovf <- 0
+BP_DEV void bp_col_shift(uint64_t& acc, uint32_t& ovf) {
+  acc = (acc >> 32) | ((uint64_t)ovf << 32);
+  ovf = 0;
+}
+
+template <class F, int K, int I>
+struct MontRedCol {  // adds m[i]*p[K-i] for i = I .. min(K,7), p index in range
+  static BP_DEV void run(uint64_t& acc, uint32_t& ovf, const uint32_t* m) {
+    if constexpr (I <= 7 && I <= K) {
+      if constexpr (K - I <= 7 && !(K < 8 && I == K))  // i == K (k < 8) is the m[k]*p[0] term, added by the caller
+        bp_mac_const<F::mod(K - I)>(acc, ovf, m[I]);
+      MontRedCol<F, K, I + 1>::run(acc, ovf, m);
+    }
+  }
+};
+
+template <class F>
+BP_DEV Fe fe_mul(const Fe& a, const Fe& b) {
+  uint64_t acc = 0;
+  uint32_t ovf = 0;
+  uint32_t m[8];
+  Fe r;
+  // low columns 0..7: choose m[k] so that the column's low word becomes zero
+#define BP_LOW_COL(K)                                                     \
+  {                                                                       \
+    _Pragma("unroll") for (int i = 0; i <= K; i++) bp_mac(acc, ovf, a.v[i], b.v[K - i]); \
+    MontRedCol<F, K, 0>::run(acc, ovf, m);                                \
+    m[K] = (uint32_t)acc * F::kInv32;                                     \
+    bp_mac_const<F::mod(0)>(acc, ovf, m[K]);                              \
+    bp_col_shift(acc, ovf);                                               \
+  }
+  BP_LOW_COL(0) BP_LOW_COL(1) BP_LOW_COL(2) BP_LOW_COL(3)
+  BP_LOW_COL(4) BP_LOW_COL(5) BP_LOW_COL(6) BP_LOW_COL(7)
+#undef BP_LOW_COL
+#define BP_HIGH_COL(K)                                                    \
+  {                                                                       \
+    _Pragma("unroll") for (int i = K - 7; i <= 7; i++) bp_mac(acc, ovf, a.v[i], b.v[K - i]); \
+    MontRedCol<F, K, K - 7>::run(acc, ovf, m);                            \
+    r.v[K - 8] = (uint32_t)acc;                                           \
+    bp_col_shift(acc, ovf);                                               \
+  }
+  BP_HIGH_COL(8) BP_HIGH_COL(9) BP_HIGH_COL(10) BP_HIGH_COL(11)
+  BP_HIGH_COL(12) BP_HIGH_COL(13) BP_HIGH_COL(14)
+#undef BP_HIGH_COL
+  r.v[7] = (uint32_t)acc;
+  return fe_reduce_once<F>(r, (uint32_t)(acc >> 32));
+}
+#else
+template <class F>
+BP_DEV Fe fe_mul(const Fe& a, const Fe& b) {
+  return fe_mul_portable<F>(a, b);
+}
+#endif
 
 template <class F>
 BP_DEV Fe fe_sqr(const Fe& a) {
