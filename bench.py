@@ -132,17 +132,16 @@ def main():
     ks = make_inputs(n, rank)
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()  # noqa: E731
     dx, dy, dk = to_dev(px), to_dev(py), to_dev(ks)
-    win = torch.zeros(64 * 16, dtype=torch.int64, device="cuda")
-    gathered = torch.zeros((world, 64 * 16), dtype=torch.int64, device="cuda") if world > 1 else None
+    from bulletproofs_amd.sharded import ShardedMsm
+
+    sharded = ShardedMsm(ctx, bp.SECP256K1, dist=dist if world > 1 else None)
+    win = sharded.win
 
     def step():
         if world == 1:
             return ctx.msm_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n)
-        nw, cb = ctx.msm_windows_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n, win.data_ptr())
-        dist.all_gather_into_tensor(gathered.view(-1), win)
-        torch.cuda.current_stream().synchronize()
-        packed = gathered[:, :nw * 16].contiguous()
-        return ctx.msm_combine_windows_dev(bp.SECP256K1, packed.data_ptr(), world, nw, cb)
+        # per-rank window sums -> one RCCL all_gather -> window-wise combine on every GPU
+        return sharded.msm(dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n)
 
     def barrier():
         if world > 1:
@@ -208,7 +207,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(1 << 17)
+            out["cpu_baseline"] = cpu_baseline(n)
         assert res is not None
         print(json.dumps(out), flush=True)
     if world > 1:

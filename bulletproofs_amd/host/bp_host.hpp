@@ -1,0 +1,278 @@
+// Host-side C++ mirror of the reference's types around the hot path, on top of the
+// C ABI (include/bp_gpu.h): the deferred-MSM accumulator `Msm` (src/msm.rs:8-115) and
+// the inner-product-argument prover / verifier loops (src/ipa/mod.rs:19-212) with the
+// Fiat-Shamir transcript supplied by the caller (spongefish is out of scope).
+// Heavy work -- every MSM, fold, dot product, s-vector -- goes through libbp_gpu; the
+// host keeps the bookkeeping the reference also keeps on the host (hash map merges,
+// a handful of single scalar multiplications per round).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <stdexcept>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/bp_gpu.h"
+#include "../csrc/bp_host_math.h"
+
+namespace bp {
+namespace host {
+
+struct Scalar {
+  uint64_t l[4];
+  bool operator==(const Scalar& o) const { return memcmp(l, o.l, 32) == 0; }
+};
+struct Affine {
+  uint64_t x[4], y[4];
+  uint8_t inf;
+  bool operator==(const Affine& o) const {
+    if (inf || o.inf) return inf && o.inf;
+    return memcmp(x, o.x, 32) == 0 && memcmp(y, o.y, 32) == 0;
+  }
+};
+struct AffineHash {
+  size_t operator()(const Affine& p) const {
+    if (p.inf) return 0x9E3779B97F4A7C15ull;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (int i = 0; i < 4; i++) h = (h ^ p.x[i]) * 0x100000001b3ull, h = (h ^ p.y[i]) * 0x100000001b3ull;
+    return (size_t)h;
+  }
+};
+struct Projective {  // normalised Jacobian as returned by the ABI
+  uint64_t xyz[12];
+};
+
+inline void check(bp_ctx* ctx, int rc, const char* what) {
+  if (rc != BP_OK) throw std::runtime_error(std::string(what) + ": " + bp_last_error(ctx));
+}
+
+// ---- scalar-field helpers (Montgomery form in and out) --------------------------
+template <class Fr>
+struct ScalarOps {
+  static HFe to(const Scalar& s) { HFe r; memcpy(r.v, s.l, 32); return r; }
+  static Scalar from(const HFe& f) { Scalar s; memcpy(s.l, f.v, 32); return s; }
+  static Scalar add(const Scalar& a, const Scalar& b) { return from(h_add<Fr>(to(a), to(b))); }
+  static Scalar mul(const Scalar& a, const Scalar& b) { return from(h_mul<Fr>(to(a), to(b))); }
+  static Scalar neg(const Scalar& a) { return from(h_neg<Fr>(to(a))); }
+  // Fermat inverse with Montgomery products: Montgomery form in, Montgomery form out
+  static Scalar inv(const Scalar& a) { return from(h_inv<Fr>(to(a))); }
+  static Scalar to_mont(const Scalar& canonical) {
+    HFe r2{{Fr::r264(0), Fr::r264(1), Fr::r264(2), Fr::r264(3)}};
+    return from(h_mul<Fr>(to(canonical), r2));
+  }
+  static Scalar one() { return from(h_one<Fr>()); }
+  static Scalar zero() { return Scalar{{0, 0, 0, 0}}; }
+};
+
+// ---- single-point helpers on the host (a few per IPA round) ----------------------
+template <class Fq, class Fr>
+struct PointOps {
+  static HXyzz lift(const Affine& p) {
+    if (p.inf) return hx_identity<Fq>();
+    HXyzz r;
+    memcpy(r.x.v, p.x, 32); memcpy(r.y.v, p.y, 32);
+    r.zz = h_one<Fq>(); r.zzz = h_one<Fq>();
+    return r;
+  }
+  static HXyzz lift(const Projective& p) {
+    HFe z; memcpy(z.v, p.xyz + 8, 32);
+    if (h_is_zero(z)) return hx_identity<Fq>();
+    Affine a; memcpy(a.x, p.xyz, 32); memcpy(a.y, p.xyz + 4, 32); a.inf = 0;  // Z == 1 by contract
+    return lift(a);
+  }
+  static HXyzz mul(const HXyzz& p, const Scalar& k_mont) {
+    HFe km; memcpy(km.v, k_mont.l, 32);
+    HFe k = h_from_mont<Fr>(km);
+    HXyzz acc = hx_identity<Fq>();
+    for (int i = 255; i >= 0; i--) {
+      acc = hx_dbl<Fq>(acc);
+      if ((k.v[i >> 6] >> (i & 63)) & 1) acc = hx_add<Fq>(acc, p);
+    }
+    return acc;
+  }
+  static Projective lower(const HXyzz& p) { Projective r; hx_to_xyz<Fq>(p, r.xyz); return r; }
+  static Affine to_affine(const Projective& p) {
+    Affine a; HFe z; memcpy(z.v, p.xyz + 8, 32);
+    a.inf = h_is_zero(z) ? 1 : 0;
+    if (a.inf) { memset(a.x, 0, 32); memset(a.y, 0, 32); } else { memcpy(a.x, p.xyz, 32); memcpy(a.y, p.xyz + 4, 32); }
+    return a;
+  }
+};
+
+// ---- Msm: src/msm.rs:8-88 ----------------------------------------------------------
+template <class Fq, class Fr, int CURVE>
+class Msm {
+ public:
+  using S = ScalarOps<Fr>;
+  explicit Msm(bp_ctx* ctx) : ctx_(ctx) {}
+  // src/msm.rs:33-38
+  void upsert(const Affine& base, const Scalar& scalar) {
+    auto it = map_.find(base);
+    if (it == map_.end()) map_.emplace(base, scalar); else it->second = S::add(it->second, scalar);
+  }
+  // src/msm.rs:41-48
+  void upsert_batch(const std::vector<Affine>& bases, const std::vector<Scalar>& scalars) {
+    size_t n = bases.size() < scalars.size() ? bases.size() : scalars.size();
+    for (size_t i = 0; i < n; i++) upsert(bases[i], scalars[i]);
+  }
+  // src/msm.rs:50-54
+  void scale(const Scalar& s) { for (auto& kv : map_) kv.second = S::mul(kv.second, s); }
+  // src/msm.rs:62-71
+  void scale_elems(const std::vector<Affine>& bases, const std::vector<Scalar>& factors) {
+    for (size_t i = 0; i < bases.size() && i < factors.size(); i++) {
+      auto it = map_.find(bases[i]);
+      if (it != map_.end()) it->second = S::mul(it->second, factors[i]);
+    }
+  }
+  // src/msm.rs:73-77
+  void batch(const Msm& rhs) { for (auto& kv : rhs.map_) upsert(kv.first, kv.second); }
+  size_t size() const { return map_.size(); }
+  // src/msm.rs:79-87: one MSM over the de-duplicated map (iteration order is unspecified
+  // there too; the group element does not depend on it)
+  Projective execute() const {
+    size_t n = map_.size();
+    std::vector<uint64_t> x(n * 4), y(n * 4), s(n * 4);
+    std::vector<uint8_t> inf(n);
+    size_t i = 0;
+    for (auto& kv : map_) {
+      memcpy(&x[4 * i], kv.first.x, 32); memcpy(&y[4 * i], kv.first.y, 32); inf[i] = kv.first.inf;
+      memcpy(&s[4 * i], kv.second.l, 32);
+      i++;
+    }
+    Projective out;
+    check(ctx_, bp_msm(ctx_, CURVE, x.data(), y.data(), inf.data(), s.data(), n, out.xyz), "bp_msm");
+    return out;
+  }
+  bp_ctx* ctx() const { return ctx_; }
+
+ private:
+  bp_ctx* ctx_;
+  std::unordered_map<Affine, Scalar, AffineHash> map_;
+};
+
+inline bool is_zero(const Projective& p) { return (p.xyz[8] | p.xyz[9] | p.xyz[10] | p.xyz[11]) == 0; }
+
+// src/msm.rs:91-115 with the random alpha supplied by the caller
+template <class M>
+bool verify_batch_aux(std::vector<M>& proofs, const Scalar& alpha) {
+  using S = typename M::S;
+  if (proofs.empty()) throw std::invalid_argument("non-empty vec");
+  Scalar pw = S::one();
+  M acc(proofs[0].ctx());
+  for (size_t k = 0; k < proofs.size(); k++) {
+    proofs[k].scale(pw);
+    acc.batch(proofs[k]);
+    pw = S::mul(pw, alpha);
+  }
+  return is_zero(acc.execute());
+}
+
+// ---- transcript stand-in -------------------------------------------------------------
+struct Transcript {
+  virtual void prover_points(const Projective* pts, size_t n) = 0;  // prover_message(&[L, R])
+  virtual void prover_scalars(const Scalar* s, size_t n) = 0;
+  virtual Scalar verifier_scalar() = 0;                              // verifier_message()
+  virtual ~Transcript() {}
+};
+
+struct IpaProof {
+  std::vector<Projective> L, R;
+  Scalar a, b;
+};
+
+template <class Fq, class Fr, int CURVE>
+struct Ipa {
+  using S = ScalarOps<Fr>;
+  using P = PointOps<Fq, Fr>;
+  struct Crs { std::vector<Affine> gs, hs; Affine u; };
+
+  static void planes(const std::vector<Affine>& v, size_t n, std::vector<uint64_t>& x, std::vector<uint64_t>& y,
+                     std::vector<uint8_t>& inf) {
+    x.resize(n * 4); y.resize(n * 4); inf.resize(n);
+    for (size_t i = 0; i < n; i++) { memcpy(&x[4 * i], v[i].x, 32); memcpy(&y[4 * i], v[i].y, 32); inf[i] = v[i].inf; }
+  }
+
+  // Witness::statement, src/ipa/types.rs:80-88: P = <a,G> + <b,H> + <a,b> u
+  static Projective statement(bp_ctx* ctx, const Crs& crs, const std::vector<Scalar>& a, const std::vector<Scalar>& b) {
+    size_t n = a.size();
+    std::vector<uint64_t> gx, gy, hx, hy; std::vector<uint8_t> gi, hi;
+    planes(crs.gs, n, gx, gy, gi); planes(crs.hs, n, hx, hy, hi);
+    Projective g, h; Scalar c;
+    check(ctx, bp_msm(ctx, CURVE, gx.data(), gy.data(), gi.data(), a[0].l, n, g.xyz), "bp_msm");
+    check(ctx, bp_msm(ctx, CURVE, hx.data(), hy.data(), hi.data(), b[0].l, n, h.xyz), "bp_msm");
+    check(ctx, bp_inner_product(ctx, CURVE, a[0].l, b[0].l, n, c.l), "bp_inner_product");
+    HXyzz p = hx_add<Fq>(hx_add<Fq>(P::lift(g), P::lift(h)), P::mul(P::lift(crs.u), c));
+    return P::lower(p);
+  }
+
+  // ipa::prove, src/ipa/mod.rs:19-99
+  static IpaProof prove(bp_ctx* ctx, const Crs& crs, const std::vector<Scalar>& a, const std::vector<Scalar>& b,
+                        Transcript& t) {
+    size_t n = a.size();
+    std::vector<uint64_t> gx, gy, hx, hy; std::vector<uint8_t> gi, hi;
+    planes(crs.gs, n, gx, gy, gi); planes(crs.hs, n, hx, hy, hi);
+    bp_ipa* s = nullptr;
+    check(ctx, bp_ipa_begin(ctx, CURVE, BP_IPA_BULLETPROOF, gx.data(), gy.data(), gi.data(), hx.data(), hy.data(),
+                            hi.data(), a[0].l, b[0].l, n, &s), "bp_ipa_begin");
+    IpaProof proof;
+    HXyzz u = P::lift(crs.u);
+    try {
+      while (bp_ipa_len(s) != 1) {
+        Projective lm, rm; Scalar cl, cr;
+        check(ctx, bp_ipa_round_lr(s, lm.xyz, rm.xyz, cl.l, cr.l), "bp_ipa_round_lr");
+        Projective lr[2] = {P::lower(hx_add<Fq>(P::mul(u, cl), P::lift(lm))),   // :43-55
+                            P::lower(hx_add<Fq>(P::mul(u, cr), P::lift(rm)))};  // :59-71
+        t.prover_points(lr, 2);                                                 // :75
+        Scalar alpha = t.verifier_scalar();                                     // :77
+        Scalar alpha_inv = S::inv(alpha);                                       // :78
+        check(ctx, bp_ipa_round_fold(s, alpha.l, alpha_inv.l), "bp_ipa_round_fold");  // :80-92
+        proof.L.push_back(lr[0]); proof.R.push_back(lr[1]);
+      }
+      check(ctx, bp_ipa_read(s, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, proof.a.l, proof.b.l), "bp_ipa_read");
+    } catch (...) { bp_ipa_free(s); throw; }
+    bp_ipa_free(s);
+    Scalar ab[2] = {proof.a, proof.b};
+    t.prover_scalars(ab, 2);                                                    // :97
+    return proof;
+  }
+
+  // ipa::verify_aux, src/ipa/mod.rs:102-193; challenges are re-derived from the transcript
+  static Msm<Fq, Fr, CURVE> verify_aux(bp_ctx* ctx, const Crs& crs, const Projective& p, size_t n, const IpaProof& proof,
+                                       Transcript& t) {
+    size_t k = proof.L.size();
+    std::vector<Scalar> xs(k), xinv(k);
+    for (size_t j = 0; j < k; j++) {
+      Projective lr[2] = {proof.L[j], proof.R[j]};
+      t.prover_points(lr, 2);
+      xs[j] = t.verifier_scalar();
+      xinv[j] = S::inv(xs[j]);                                                  // batch_inversion :128-132
+    }
+    Msm<Fq, Fr, CURVE> msm(ctx);
+    msm.upsert(crs.u, S::mul(proof.a, proof.b));                                // :125
+    std::vector<Scalar> ss(n), ssi(n);
+    if (k) {
+      check(ctx, bp_s_vector(ctx, CURVE, xs[0].l, xinv[0].l, k, ss[0].l), "bp_s_vector");   // :134-148
+      check(ctx, bp_s_vector(ctx, CURVE, xinv[0].l, xs[0].l, k, ssi[0].l), "bp_s_vector");  // :150-154
+    } else {
+      ss[0] = S::one(); ssi[0] = S::one();
+    }
+    std::vector<Scalar> as(n), bs(n);
+    check(ctx, bp_vec_op(ctx, CURVE, BP_VEC_SCALE, ss[0].l, nullptr, proof.a.l, n, as[0].l), "bp_vec_op");   // :160
+    check(ctx, bp_vec_op(ctx, CURVE, BP_VEC_SCALE, ssi[0].l, nullptr, proof.b.l, n, bs[0].l), "bp_vec_op");  // :166
+    std::vector<Affine> gs(crs.gs.begin(), crs.gs.begin() + n), hs(crs.hs.begin(), crs.hs.begin() + n);
+    msm.upsert_batch(gs, as);
+    msm.upsert_batch(hs, bs);
+    // :170-190: -(P + sum x_j^2 L_j + x_j^-2 R_j)
+    Scalar minus_one = S::neg(S::one());
+    msm.upsert(P::to_affine(p), minus_one);
+    for (size_t j = 0; j < k; j++) {
+      msm.upsert(P::to_affine(proof.L[j]), S::mul(minus_one, S::mul(xs[j], xs[j])));
+      msm.upsert(P::to_affine(proof.R[j]), S::mul(minus_one, S::mul(xinv[j], xinv[j])));
+    }
+    return msm;
+  }
+};
+
+}  // namespace host
+}  // namespace bp

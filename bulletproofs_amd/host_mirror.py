@@ -1,0 +1,58 @@
+"""ctypes access to libbp_host.so: the C++ host mirror of the reference's `Msm`
+accumulator (src/msm.rs) and IPA prover/verifier loops (src/ipa/mod.rs), which
+drive libbp_gpu through the C ABI.  Used by the parity tests."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib  # loads the HIP runtime and libbp_gpu.so first
+from .api import Context, _f, _p, _pts
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbp_host.so")
+if not os.path.exists(_PATH):
+    raise ImportError(f"{_PATH} not found: build it with `make -C bulletproofs_amd/host`")
+hlib = C.CDLL(_PATH)
+vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+hlib.bph_msm_accumulate.restype = ci
+hlib.bph_msm_accumulate.argtypes = [vp, ci, vp, vp, vp, vp, sz, vp, C.POINTER(sz)]
+hlib.bph_ipa_roundtrip.restype = ci
+hlib.bph_ipa_roundtrip.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, sz, C.c_uint64, ci, vp, vp, vp, vp,
+                                   C.POINTER(ci), C.POINTER(ci)]
+
+
+def msm_accumulate(ctx: Context, curve, bases, scalars):
+    """Msm::from_iter + execute: duplicate bases merge by adding scalars."""
+    x, y, inf = _pts(bases)
+    s = _f(scalars)
+    out = np.zeros(12, dtype=np.uint64)
+    distinct = sz()
+    rc = hlib.bph_msm_accumulate(ctx.h, curve, _p(x), _p(y), _p(inf), _p(s), x.shape[0], _p(out), C.byref(distinct))
+    if rc:
+        raise RuntimeError(f"bph_msm_accumulate rc={rc}")
+    return out, distinct.value
+
+
+def ipa_roundtrip(ctx: Context, curve, gs, hs, u_xy, a, b, n_proofs=1, seed=1, tamper=False):
+    """statement + ipa::prove + ipa::verify (+ verify_batch_aux) with the seeded transcript stand-in."""
+    gx, gy, _ = _pts(gs)
+    hx, hy, _ = _pts(hs)
+    a, b = _f(a), _f(b)
+    n = gx.shape[0]
+    assert a.shape[0] == n * n_proofs and b.shape[0] == n * n_proofs
+    k = n.bit_length() - 1
+    u_xy = np.ascontiguousarray(u_xy, dtype=np.uint64).reshape(8)
+    out_l = np.zeros((max(k, 1), 12), dtype=np.uint64)
+    out_r = np.zeros((max(k, 1), 12), dtype=np.uint64)
+    out_ab = np.zeros(8, dtype=np.uint64)
+    out_p = np.zeros(12, dtype=np.uint64)
+    ok1, okb = ci(), ci()
+    rc = hlib.bph_ipa_roundtrip(ctx.h, curve, _p(gx), _p(gy), _p(hx), _p(hy), _p(u_xy), _p(a), _p(b), n, n_proofs,
+                                seed, int(tamper), _p(out_l), _p(out_r), _p(out_ab), _p(out_p), C.byref(ok1),
+                                C.byref(okb))
+    if rc:
+        raise RuntimeError(f"bph_ipa_roundtrip rc={rc}")
+    return dict(L=out_l[:k], R=out_r[:k], a=out_ab[:4], b=out_ab[4:], P=out_p, single_ok=bool(ok1.value),
+                batch_ok=bool(okb.value))

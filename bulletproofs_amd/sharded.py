@@ -1,0 +1,56 @@
+"""Multi-GPU MSM: one process per GPU, points partitioned by range, one all-gather.
+
+An MSM is a sum over independent (point, scalar) pairs, so each rank runs the whole
+single-GPU pipeline on its range and keeps its per-window partial sums on the device;
+the partials (n_windows x 128 B per rank) are exchanged with ONE all_gather
+(torch.distributed; backend "nccl" is RCCL over xGMI) and every rank combines them
+window by window on its GPU.  Curve addition is not an RCCL reduction operator, hence
+all-gather + combine rather than all-reduce.
+"""
+from __future__ import annotations
+
+MAX_WINDOWS = 64
+WINDOW_U64 = 16  # one XYZZ point
+
+
+def shard_range(n: int, rank: int, world: int):
+    """[begin, end) of the points rank owns: contiguous ranges, sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+class ShardedMsm:
+    def __init__(self, ctx, curve, dist=None, device="cuda", local_windows=None, combine=None):
+        """local_windows(d_x, d_y, d_inf, d_s, n, out_tensor) -> (n_windows, window_bits) and
+        combine(gathered_tensor, world, n_windows, window_bits) -> xyz default to the library's
+        device entry points; tests on CPU inject oracle-backed stand-ins."""
+        import torch
+
+        self.torch = torch
+        self.ctx, self.curve, self.dist = ctx, curve, dist
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.win = torch.zeros(MAX_WINDOWS * WINDOW_U64, dtype=torch.int64, device=device)
+        self.gathered = torch.zeros((self.world, MAX_WINDOWS * WINDOW_U64), dtype=torch.int64, device=device)
+        self._local = local_windows or self._local_dev
+        self._combine = combine or self._combine_dev
+
+    def _local_dev(self, d_x, d_y, d_inf, d_s, n, out):
+        return self.ctx.msm_windows_dev(self.curve, d_x, d_y, d_inf, d_s, n, out.data_ptr())
+
+    def _combine_dev(self, gathered, world, nw, cb):
+        packed = gathered[:, :nw * WINDOW_U64].contiguous()
+        return self.ctx.msm_combine_windows_dev(self.curve, packed.data_ptr(), world, nw, cb)
+
+    def msm(self, d_x, d_y, d_inf, d_s, n_local):
+        nw, cb = self._local(d_x, d_y, d_inf, d_s, n_local, self.win)
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.gathered.view(-1), self.win)
+            if self.gathered.is_cuda:
+                self.torch.cuda.current_stream().synchronize()
+        else:
+            self.gathered[0].copy_(self.win)
+            if self.gathered.is_cuda:
+                self.torch.cuda.current_stream().synchronize()
+        return self._combine(self.gathered, self.world, nw, cb)
