@@ -19,7 +19,7 @@ enum Slot {
   S_IN0, S_IN1, S_IN2, S_IN3, S_IN4, S_IN5, S_IN6,
   S_OUT0, S_OUT1, S_OUT2,
   S_KEYS_A, S_KEYS_B, S_VALS_A, S_VALS_B, S_SORT_TMP, S_BSTART, S_BEND, S_BUCKETS, S_SEGS,
-  S_WINDOWS, S_TABLE, S_SMALL, S_NCH, S_CHOFF, S_SCAN_TMP, S_CHUNK_SUMS, S_HEAVY, S_COUNT
+  S_WINDOWS, S_TABLE, S_SMALL, S_NCH, S_CHOFF, S_SCAN_TMP, S_CHUNK_SUMS, S_HEAVY, S_CKEY_A, S_CKEY_B, S_CVAL_A, S_CVAL_B, S_DESC_B, S_DESC_S, S_CSORT_TMP, S_COUNT
 };
 
 struct DevBuf {
@@ -180,6 +180,13 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
   CHK(reserve(ctx, S_CHOFF, plan->nch_bytes, &p)); ws.choff = (u32*)p;
   CHK(reserve(ctx, S_SCAN_TMP, plan->scan_tmp_bytes, &p)); ws.scan_tmp = p;
   CHK(reserve(ctx, S_CHUNK_SUMS, plan->chunk_sum_bytes, &p)); ws.chunk_sums = (u32*)p;
+  CHK(reserve(ctx, S_CKEY_A, plan->cdesc_bytes, &p)); ws.ckey_a = (u32*)p;
+  CHK(reserve(ctx, S_CKEY_B, plan->cdesc_bytes, &p)); ws.ckey_b = (u32*)p;
+  CHK(reserve(ctx, S_CVAL_A, plan->cdesc_bytes, &p)); ws.cval_a = (u32*)p;
+  CHK(reserve(ctx, S_CVAL_B, plan->cdesc_bytes, &p)); ws.cval_b = (u32*)p;
+  CHK(reserve(ctx, S_DESC_B, plan->cdesc_bytes, &p)); ws.desc_b = (u32*)p;
+  CHK(reserve(ctx, S_DESC_S, plan->cdesc_bytes, &p)); ws.desc_s = (u32*)p;
+  CHK(reserve(ctx, S_CSORT_TMP, plan->csort_tmp_bytes, &p)); ws.csort_tmp = p;
   CHK(reserve(ctx, S_HEAVY, plan->nch_bytes + 256, &p)); ws.heavy = (u32*)p + 64; ws.heavy_count = (u32*)p;
   CHK(reserve(ctx, S_SEGS, plan->seg_bytes, &p)); ws.segs = (u32*)p;
   CHK(reserve(ctx, S_WINDOWS, plan->win_bytes, &p)); ws.windows = (u32*)p;

@@ -70,7 +70,7 @@ struct MsmPlan {
   size_t entries; // W * n_total
   // workspace sizes in bytes
   size_t keys_bytes, sort_tmp_bytes, bounds_bytes, bucket_bytes, seg_bytes, win_bytes;
-  size_t scan_tmp_bytes, nch_bytes, chunk_sum_bytes;
+  size_t scan_tmp_bytes, nch_bytes, chunk_sum_bytes, cdesc_bytes, csort_tmp_bytes;
   u32 chunk;      // max sorted entries per accumulation chunk
   size_t nc_cap;  // upper bound on the number of chunks
   int seg_len;    // buckets per reduction segment
@@ -92,6 +92,9 @@ struct MsmWorkspace {
   u32* choff;         // exclusive scan of nch
   void* scan_tmp;
   u32* chunk_sums;    // XYZZ SoA: 4 planes * nc_cap * 8 u32
+  u32 *ckey_a, *ckey_b, *cval_a, *cval_b;  // chunk-length sort (nc_cap each)
+  u32 *desc_b, *desc_s;                    // chunk -> bucket, first sorted position
+  void* csort_tmp;
   u32* heavy;         // queue of buckets with many chunks (W*NB)
   u32* heavy_count;
   u32* buckets;       // XYZZ SoA: 4 planes * (W*NB) * 8 u32

@@ -36,6 +36,9 @@ namespace bp {
       return hipErrorInvalidValue;               \
   }
 
+constexpr u32 kChunkKeyInvalid = 63;  // sort key of the unused tail of the chunk table
+constexpr int kChunkKeyBits = 6;
+
 static inline int ilog2_floor(size_t n) {
   int l = 0;
   while (n >>= 1) l++;
@@ -94,6 +97,12 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, MsmPlan* pla
   e = rocprim::exclusive_scan(nullptr, tmp, (u32*)nullptr, (u32*)nullptr, 0u, nbt + 1, rocprim::plus<u32>(), 0, false);
   if (e != hipSuccess) return e;
   p.scan_tmp_bytes = (tmp + 255) & ~(size_t)255;
+  p.cdesc_bytes = ((p.nc_cap * sizeof(u32)) + 255) & ~(size_t)255;
+  tmp = 0;
+  e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
+      nullptr, tmp, nullptr, nullptr, nullptr, nullptr, p.nc_cap, 0, kChunkKeyBits, 0, false);
+  if (e != hipSuccess) return e;
+  p.csort_tmp_bytes = (tmp + 255) & ~(size_t)255;
   *plan = p;
   return hipSuccess;
 }
@@ -218,31 +227,57 @@ __global__ __launch_bounds__(256) void k_chunk_counts(const u32* __restrict__ st
   nch[b] = b < nbt ? (end[b] - start[b] + chunk - 1) / chunk : 0;
 }
 
+// Chunk descriptors: for chunk t its bucket, first sorted position and a sort key
+// (chunk - length, so that longer chunks come first; kChunkKeyInvalid past the
+// last chunk).  Sorting the chunk ids by that key gives every wave chunks of equal
+// length, which removes the SIMD idle time of uneven chunks.
+
+__global__ __launch_bounds__(256) void k_chunk_desc(const u32* __restrict__ start, const u32* __restrict__ end,
+                                                    const u32* __restrict__ choff, size_t nbt, u32 chunk,
+                                                    size_t nc_cap, u32* __restrict__ ckey,
+                                                    u32* __restrict__ cval, u32* __restrict__ desc_b,
+                                                    u32* __restrict__ desc_s) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nc_cap) return;
+  u32 nc = choff[nbt];
+  cval[t] = (u32)t;
+  if (t >= nc) {
+    ckey[t] = kChunkKeyInvalid;
+    return;
+  }
+  size_t lo = 0, hi = nbt;  // last bucket b with choff[b] <= t: choff[lo] <= t < choff[hi]
+  while (hi - lo > 1) {
+    size_t mid = (lo + hi) >> 1;
+    if (choff[mid] <= (u32)t) lo = mid; else hi = mid;
+  }
+  u32 k = (u32)t - choff[lo];
+  u32 s = start[lo] + k * chunk, e = end[lo];
+  u32 len = e - s > chunk ? chunk : e - s;
+  desc_b[t] = (u32)lo;
+  desc_s[t] = s;
+  ckey[t] = chunk - len;
+}
+
 template <class C>
 __global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ x0, const u32* __restrict__ y0,
                                                     size_t n0, const u32* __restrict__ x1,
                                                     const u32* __restrict__ y1,
                                                     const u32* __restrict__ vals,
-                                                    const u32* __restrict__ start,
-                                                    const u32* __restrict__ end,
-                                                    const u32* __restrict__ choff, size_t nbt, u32 chunk,
+                                                    const u32* __restrict__ ckey,
+                                                    const u32* __restrict__ cval,
+                                                    const u32* __restrict__ desc_b,
+                                                    const u32* __restrict__ desc_s,
+                                                    const u32* __restrict__ nch, size_t nbt, u32 chunk,
                                                     size_t nc_cap, u32* __restrict__ buckets,
                                                     u32* __restrict__ chunk_sums) {
   using F = typename C::Fq;
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  u32 nc = choff[nbt];
-  if (t >= nc) return;
-  // last bucket b with choff[b] <= t
-  size_t lo = 0, hi = nbt;  // invariant: choff[lo] <= t < choff[hi]
-  while (hi - lo > 1) {
-    size_t mid = (lo + hi) >> 1;
-    if (choff[mid] <= (u32)t) lo = mid; else hi = mid;
-  }
-  size_t b = lo;
-  u32 k = (u32)t - choff[b];
-  u32 s = start[b] + k * chunk, e = end[b];
-  bool single = (e - start[b]) <= chunk;
-  if (e - s > chunk) e = s + chunk;
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nc_cap) return;
+  u32 key = ckey[j];
+  if (key == kChunkKeyInvalid) return;
+  u32 t = cval[j];
+  u32 b = desc_b[t];
+  u32 s = desc_s[t], e = s + (chunk - key);
   Xyzz acc = xyzz_identity<F>();
   for (u32 p = s; p < e; p++) {
     u32 v = vals[p];
@@ -254,7 +289,7 @@ __global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ x0, 
     if (v >> 31) qy = fe_neg<F>(qy);
     xyzz_madd<F>(acc, qx, qy);
   }
-  if (single)
+  if (nch[b] == 1)
     xyzz_store_soa(buckets, nbt, b, acc);
   else
     xyzz_store_soa(chunk_sums, nc_cap, t, acc);
@@ -431,10 +466,17 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPla
   e = rocprim::exclusive_scan(ws.scan_tmp, tmp, ws.nch, ws.choff, 0u, nbt + 1, rocprim::plus<u32>(), st, false);
   if (e != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.heavy_count, 0, sizeof(u32), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_chunk_desc, dim3((unsigned)((plan.nc_cap + 255) / 256)), dim3(256), 0, st, ws.bucket_start,
+                     ws.bucket_end, ws.choff, nbt, plan.chunk, plan.nc_cap, ws.ckey_a, ws.cval_a, ws.desc_b, ws.desc_s);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  tmp = plan.csort_tmp_bytes;
+  e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
+      ws.csort_tmp, tmp, ws.ckey_a, ws.ckey_b, ws.cval_a, ws.cval_b, plan.nc_cap, 0, kChunkKeyBits, st, false);
+  if (e != hipSuccess) return e;
   if (ev_acc0 && (e = hipEventRecord(ev_acc0, st)) != hipSuccess) return e;
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_chunk_sums<C>, dim3((unsigned)((plan.nc_cap + 127) / 128)), dim3(128),
-                                           0, st, p0.x, p0.y, p0.n, p1.x, p1.y, ws.vals_b, ws.bucket_start,
-                                           ws.bucket_end, ws.choff, nbt, plan.chunk, plan.nc_cap, ws.buckets,
+                                           0, st, p0.x, p0.y, p0.n, p1.x, p1.y, ws.vals_b, ws.ckey_b, ws.cval_b,
+                                           ws.desc_b, ws.desc_s, ws.nch, nbt, plan.chunk, plan.nc_cap, ws.buckets,
                                            ws.chunk_sums));
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;
