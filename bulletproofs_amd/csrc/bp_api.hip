@@ -19,7 +19,7 @@ enum Slot {
   S_IN0, S_IN1, S_IN2, S_IN3, S_IN4, S_IN5, S_IN6,
   S_OUT0, S_OUT1, S_OUT2,
   S_KEYS_A, S_KEYS_B, S_VALS_A, S_VALS_B, S_SORT_TMP, S_BSTART, S_BEND, S_BUCKETS, S_SEGS,
-  S_WINDOWS, S_TABLE, S_SMALL, S_NCH, S_CHOFF, S_SCAN_TMP, S_CHUNK_SUMS, S_HEAVY, S_CKEY_A, S_CKEY_B, S_CVAL_A, S_CVAL_B, S_DESC_B, S_DESC_S, S_CSORT_TMP, S_COUNT
+  S_WINDOWS, S_TABLE, S_SMALL, S_NCH, S_CHOFF, S_SCAN_TMP, S_CHUNK_SUMS, S_HEAVY, S_CKEY_A, S_CKEY_B, S_CVAL_A, S_CVAL_B, S_DESC_B, S_DESC_S, S_CSORT_TMP, S_SEG_GROUPS, S_COUNT
 };
 
 struct DevBuf {
@@ -189,6 +189,7 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
   CHK(reserve(ctx, S_CSORT_TMP, plan->csort_tmp_bytes, &p)); ws.csort_tmp = p;
   CHK(reserve(ctx, S_HEAVY, plan->nch_bytes + 256, &p)); ws.heavy = (u32*)p + 64; ws.heavy_count = (u32*)p;
   CHK(reserve(ctx, S_SEGS, plan->seg_bytes, &p)); ws.segs = (u32*)p;
+  CHK(reserve(ctx, S_SEG_GROUPS, plan->seg_group_bytes, &p)); ws.seg_groups = (u32*)p;
   CHK(reserve(ctx, S_WINDOWS, plan->win_bytes, &p)); ws.windows = (u32*)p;
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   e = msm_run(curve, p0, p1, *plan, ws, ctx->stream, ctx->ev[2], ctx->ev[3]);

@@ -165,84 +165,16 @@ BP_DEV Fe fe_mul_portable(const Fe& a, const Fe& b) {
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// Device form: product scanning (column by column).  A column's partial products
-// are summed into a 96-bit accumulator {acc (64 bits), ovf (32 bits)}: each
-// product is one v_mad_u64_u32 whose 64-bit addend is the accumulator itself,
-// followed by one v_addc_co_u32 that counts the carry-out.  Two instructions per
-// 32x32 product, no register shuffling inside a column.
-BP_DEV void bp_mac(uint64_t& acc, uint32_t& ovf, uint32_t a, uint32_t b) {
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(acc), "+v"(ovf)
-      : "v"(a), "v"(b)
-      : "vcc");
-}
-// multiplier is a compile-time constant: SGPR operand, or the inline constant -1
-template <uint32_t K>
-BP_DEV void bp_mac_const(uint64_t& acc, uint32_t& ovf, uint32_t a) {
-  if constexpr (K == 0xffffffffu) {
-    asm("v_mad_u64_u32 %0, vcc, %2, -1, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-        : "+v"(acc), "+v"(ovf)
-        : "v"(a)
-        : "vcc");
-  } else if constexpr (K == 1u) {
-    asm("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-        : "+v"(acc), "+v"(ovf)
-        : "v"(a)
-        : "vcc");
-  } else if constexpr (K != 0u) {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-        : "+v"(acc), "+v"(ovf)
-        : "v"(a), "s"(K)
-        : "vcc");
-  }
-}
-// next column: acc <- {acc.hi, ovf}, ovf <- 0
-BP_DEV void bp_col_shift(uint64_t& acc, uint32_t& ovf) {
-  acc = (acc >> 32) | ((uint64_t)ovf << 32);
-  ovf = 0;
-}
-
-template <class F, int K, int I>
-struct MontRedCol {  // adds m[i]*p[K-i] for i = I .. min(K,7), p index in range
-  static BP_DEV void run(uint64_t& acc, uint32_t& ovf, const uint32_t* m) {
-    if constexpr (I <= 7 && I <= K) {
-      if constexpr (K - I <= 7 && !(K < 8 && I == K))  // i == K (k < 8) is the m[k]*p[0] term, added by the caller
-        bp_mac_const<F::mod(K - I)>(acc, ovf, m[I]);
-      MontRedCol<F, K, I + 1>::run(acc, ovf, m);
-    }
-  }
-};
+// Device form: product scanning (column by column) in straight-line inline asm,
+// generated per field by tools/gen_fe_mul.py.  A column's partial products are
+// summed into a 96-bit accumulator {acc (64 bits), ovf (32 bits)}: each product is
+// one v_mad_u64_u32 whose 64-bit addend is the accumulator itself, followed by one
+// v_addc_co_u32 that counts the carry-out: two instructions per 32x32 product.
+#include "bp_field_mul_gen.h"
 
 template <class F>
 BP_DEV Fe fe_mul(const Fe& a, const Fe& b) {
-  uint64_t acc = 0;
-  uint32_t ovf = 0;
-  uint32_t m[8];
-  Fe r;
-  // low columns 0..7: choose m[k] so that the column's low word becomes zero
-#define BP_LOW_COL(K)                                                     \
-  {                                                                       \
-    _Pragma("unroll") for (int i = 0; i <= K; i++) bp_mac(acc, ovf, a.v[i], b.v[K - i]); \
-    MontRedCol<F, K, 0>::run(acc, ovf, m);                                \
-    m[K] = (uint32_t)acc * F::kInv32;                                     \
-    bp_mac_const<F::mod(0)>(acc, ovf, m[K]);                              \
-    bp_col_shift(acc, ovf);                                               \
-  }
-  BP_LOW_COL(0) BP_LOW_COL(1) BP_LOW_COL(2) BP_LOW_COL(3)
-  BP_LOW_COL(4) BP_LOW_COL(5) BP_LOW_COL(6) BP_LOW_COL(7)
-#undef BP_LOW_COL
-#define BP_HIGH_COL(K)                                                    \
-  {                                                                       \
-    _Pragma("unroll") for (int i = K - 7; i <= 7; i++) bp_mac(acc, ovf, a.v[i], b.v[K - i]); \
-    MontRedCol<F, K, K - 7>::run(acc, ovf, m);                            \
-    r.v[K - 8] = (uint32_t)acc;                                           \
-    bp_col_shift(acc, ovf);                                               \
-  }
-  BP_HIGH_COL(8) BP_HIGH_COL(9) BP_HIGH_COL(10) BP_HIGH_COL(11)
-  BP_HIGH_COL(12) BP_HIGH_COL(13) BP_HIGH_COL(14)
-#undef BP_HIGH_COL
-  r.v[7] = (uint32_t)acc;
-  return fe_reduce_once<F>(r, (uint32_t)(acc >> 32));
+  return fe_mul_dev<F>(a, b);
 }
 #else
 template <class F>

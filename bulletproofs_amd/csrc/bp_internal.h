@@ -69,7 +69,7 @@ struct MsmPlan {
   size_t n_total; // points over both parts
   size_t entries; // W * n_total
   // workspace sizes in bytes
-  size_t keys_bytes, sort_tmp_bytes, bounds_bytes, bucket_bytes, seg_bytes, win_bytes;
+  size_t keys_bytes, sort_tmp_bytes, bounds_bytes, bucket_bytes, seg_bytes, seg_group_bytes, win_bytes;
   size_t scan_tmp_bytes, nch_bytes, chunk_sum_bytes, cdesc_bytes, csort_tmp_bytes;
   u32 chunk;      // max sorted entries per accumulation chunk
   size_t nc_cap;  // upper bound on the number of chunks
@@ -99,6 +99,7 @@ struct MsmWorkspace {
   u32* heavy_count;
   u32* buckets;       // XYZZ SoA: 4 planes * (W*NB) * 8 u32
   u32* segs;          // XYZZ AoS: W * n_segs * 32 u32
+  u32* seg_groups;    // XYZZ AoS: partial sums of 1024 segments
   u32* windows;       // XYZZ AoS: W * 32 u32
 };
 

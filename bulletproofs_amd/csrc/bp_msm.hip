@@ -78,6 +78,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, MsmPlan* pla
   p.bounds_bytes = ((nbt + 2) * sizeof(u32) + 255) & ~(size_t)255;
   p.bucket_bytes = nbt * 4 * 32;
   p.seg_bytes = (size_t)p.n_windows * p.n_segs * 128;
+  p.seg_group_bytes = (size_t)p.n_windows * (p.n_segs / 1024 + 1) * 128;
   p.win_bytes = (size_t)p.n_windows * 128;
   size_t tmp = 0;
   u32 max_key = (u32)nbt;
@@ -389,21 +390,25 @@ __global__ __launch_bounds__(128) void k_reduce_segments(const u32* __restrict__
   xyzz_store_aos(segs + t * 32, acc);
 }
 
-// one block per window: sum of n_segs XYZZ points
+// Block b sums `count` consecutive XYZZ points (AoS) starting at in + b*count:
+// every lane first adds its strided share serially, then a tree over the lanes that
+// hold data (depth = ceil(count/256) - 1 + log2(min(count, 256)) additions).
 template <class C>
-__global__ __launch_bounds__(256) void k_reduce_windows(const u32* __restrict__ segs, u32 n_segs,
-                                                        u32* __restrict__ windows) {
+__global__ __launch_bounds__(256) void k_group_sum(const u32* __restrict__ in, u32 count,
+                                                   u32* __restrict__ out) {
   using F = typename C::Fq;
   __shared__ u32 lds[256 * 32];
-  u32 w = blockIdx.x;
+  const u32* base = in + (size_t)blockIdx.x * count * 32;
   Xyzz acc = xyzz_identity<F>();
-  for (u32 s = threadIdx.x; s < n_segs; s += blockDim.x) {
-    Xyzz v = xyzz_load_aos(segs + ((size_t)w * n_segs + s) * 32);
+  for (u32 s = threadIdx.x; s < count; s += blockDim.x) {
+    Xyzz v = xyzz_load_aos(base + (size_t)s * 32);
     xyzz_add<F>(acc, v);
   }
   xyzz_store_aos(lds + threadIdx.x * 32, acc);
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  int top = 128;
+  while (top >= 2 && (u32)top >= count) top >>= 1;  // lanes >= count hold the identity
+  for (int off = top; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) {
       Xyzz o = xyzz_load_aos(lds + (threadIdx.x + off) * 32);
       xyzz_add<F>(acc, o);
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(256) void k_reduce_windows(const u32* __restrict__ 
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) xyzz_store_aos(windows + (size_t)w * 32, acc);
+  if (threadIdx.x == 0) xyzz_store_aos(out + (size_t)blockIdx.x * 32, acc);
 }
 
 // window-wise sum over parts (multi-GPU combine): out[w] = sum_p in[p][w]
@@ -492,8 +497,14 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPla
     hipLaunchKernelGGL(k_reduce_segments<C>, dim3((unsigned)((nseg_threads + 127) / 128)), dim3(128), 0, st,
                        ws.buckets, nbt, plan.n_buckets, plan.seg_len, plan.n_segs, plan.n_windows,
                        ws.segs);
-    hipLaunchKernelGGL(k_reduce_windows<C>, dim3(plan.n_windows), dim3(256), 0, st, ws.segs, plan.n_segs,
-                       ws.windows);
+    // window value = sum of its segment values, in one or two tree stages
+    if (plan.n_segs > 1024) {
+      u32 groups = plan.n_segs / 1024;  // n_segs is a power of two
+      hipLaunchKernelGGL(k_group_sum<C>, dim3(plan.n_windows * groups), dim3(256), 0, st, ws.segs, 1024u, ws.seg_groups);
+      hipLaunchKernelGGL(k_group_sum<C>, dim3(plan.n_windows), dim3(256), 0, st, ws.seg_groups, groups, ws.windows);
+    } else {
+      hipLaunchKernelGGL(k_group_sum<C>, dim3(plan.n_windows), dim3(256), 0, st, ws.segs, plan.n_segs, ws.windows);
+    }
   });
   return hipGetLastError();
 }
