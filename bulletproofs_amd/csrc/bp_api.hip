@@ -785,18 +785,18 @@ int bp_ipa_round_fold(bp_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]) {
   hipError_t e;
   // Outputs overwrite the low halves in place: output i reads only inputs i and i+h.
   // G' = x^-1*G_lo + x*G_hi (both variants: src/ipa/mod.rs:81, src/poly_commit/mod.rs:102)
-  e = launch_fold_generators(s->curve, s->gx, s->gy, s->ginf, s->gx + h * 8, s->gy + h * 8, s->ginf + h, h, xic, xc,
-                             s->gx, s->gy, s->ginf, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_generators(G)", e);
+  FoldJob jg{s->gx, s->gy, s->ginf, s->gx + h * 8, s->gy + h * 8, s->ginf + h, s->gx, s->gy, s->ginf, xic, xc};
   if (s->variant == BP_IPA_BULLETPROOF) {
-    // H' = x*H_lo + x^-1*H_hi (src/ipa/mod.rs:82)
-    e = launch_fold_generators(s->curve, s->hx, s->hy, s->hinf, s->hx + h * 8, s->hy + h * 8, s->hinf + h, h, xc, xic,
-                               s->hx, s->hy, s->hinf, ctx->stream);
-    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_generators(H)", e);
+    // H' = x*H_lo + x^-1*H_hi (src/ipa/mod.rs:82), same launch as the G fold
+    FoldJob jh{s->hx, s->hy, s->hinf, s->hx + h * 8, s->hy + h * 8, s->hinf + h, s->hx, s->hy, s->hinf, xc, xic};
+    e = launch_fold_generators2(s->curve, jg, jh, h, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_generators(G,H)", e);
     // a' = a_lo*x + a_hi*x^-1 ; b' = b_lo*x^-1 + b_hi*x (src/ipa/mod.rs:88-89)
     e = launch_fold_scalars(s->curve, s->a, s->a + h * 8, h, xm, xim, s->a, ctx->stream);
     if (e == hipSuccess) e = launch_fold_scalars(s->curve, s->b, s->b + h * 8, h, xim, xm, s->b, ctx->stream);
   } else {
+    e = launch_fold_generators2(s->curve, jg, FoldJob{}, h, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_generators(G)", e);
     // a' = a_hi*u^-1 + a_lo*u ; b' = b_lo*u^-1 + b_hi*u (src/poly_commit/mod.rs:96-97)
     e = launch_fold_scalars(s->curve, s->a + h * 8, s->a, h, xim, xm, s->a, ctx->stream);
     if (e == hipSuccess) e = launch_fold_scalars(s->curve, s->b, s->b + h * 8, h, xim, xm, s->b, ctx->stream);

@@ -24,35 +24,38 @@ namespace bp {
 // out[i] = x*L[i] + y*R[i]  (src/ipa/mod.rs:215-227).  x, y arrive as canonical
 // 256-bit integers; Shamir's trick over their joint bits with the per-thread
 // table {L, R, L+R} (L+R normalised to affine so every add is a mixed add).
+// Up to two independent folds (the G and H folds of one IPA round) share a launch:
+// the kernel is bound by the latency of its ~450-step dependent chain, not by
+// throughput, until h reaches several 10^5.
 template <class C>
-__global__ __launch_bounds__(128) void k_fold_generators(
-    const u32* __restrict__ lx, const u32* __restrict__ ly, const uint8_t* __restrict__ linf,
-    const u32* __restrict__ rx, const u32* __restrict__ ry, const uint8_t* __restrict__ rinf,
-    size_t h, FeArg xs, FeArg ys, u32* __restrict__ ox, u32* __restrict__ oy,
-    uint8_t* __restrict__ oinf) {
+__global__ __launch_bounds__(128) void k_fold_generators(FoldJob j0, FoldJob j1, size_t h) {
   using F = typename C::Fq;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= h) return;
-  bool l_inf = linf && linf[i];
-  bool r_inf = rinf && rinf[i];
-  Fe Lx = fe_load(lx + i * 8), Ly = fe_load(ly + i * 8);
-  Fe Rx = fe_load(rx + i * 8), Ry = fe_load(ry + i * 8);
+  // a block belongs to one job, so the bit schedule stays uniform within a wave
+  const unsigned blocks_per_job = (unsigned)((h + blockDim.x - 1) / blockDim.x);
+  const bool second = blockIdx.x >= blocks_per_job;
+  const FoldJob& jb = second ? j1 : j0;
+  size_t i = (size_t)(blockIdx.x - (second ? blocks_per_job : 0)) * blockDim.x + threadIdx.x;
+  if (i >= h || jb.lx == nullptr) return;
+  bool l_inf = jb.linf && jb.linf[i];
+  bool r_inf = jb.rinf && jb.rinf[i];
+  Fe Lx = fe_load(jb.lx + i * 8), Ly = fe_load(jb.ly + i * 8);
+  Fe Rx = fe_load(jb.rx + i * 8), Ry = fe_load(jb.ry + i * 8);
   // T = L + R in affine (or flagged identity)
   Fe Tx, Ty;
   bool t_inf;
   {
-    Jac t = jac_identity<F>();
-    if (!l_inf) jac_madd<F>(t, Lx, Ly);
-    if (!r_inf) jac_madd<F>(t, Rx, Ry);
-    t_inf = jac_to_affine<F>(t, Tx, Ty);
+    Jac tj = jac_identity<F>();
+    if (!l_inf) jac_madd<F>(tj, Lx, Ly);
+    if (!r_inf) jac_madd<F>(tj, Rx, Ry);
+    t_inf = jac_to_affine<F>(tj, Tx, Ty);
   }
   Jac acc = jac_identity<F>();
   for (int w = 7; w >= 0; w--) {
-    u32 xw = xs.v[w], yw = ys.v[w];
+    u32 xw = second ? j1.x.v[w] : j0.x.v[w], yw = second ? j1.y.v[w] : j0.y.v[w];
     for (int b = 31; b >= 0; b--) {
       acc = jac_dbl<F>(acc);
       u32 sel = ((xw >> b) & 1) | (((yw >> b) & 1) << 1);
-      if (sel) {  // wave-uniform
+      if (sel) {  // uniform within a job
         Fe qx = fe_select(sel == 1, Lx, fe_select(sel == 2, Rx, Tx));
         Fe qy = fe_select(sel == 1, Ly, fe_select(sel == 2, Ry, Ty));
         bool q_inf = sel == 1 ? l_inf : (sel == 2 ? r_inf : t_inf);
@@ -62,20 +65,24 @@ __global__ __launch_bounds__(128) void k_fold_generators(
   }
   Fe X, Y;
   bool inf = jac_to_affine<F>(acc, X, Y);
-  fe_store(ox + i * 8, X);
-  fe_store(oy + i * 8, Y);
-  if (oinf) oinf[i] = inf ? 1 : 0;
+  fe_store(jb.ox + i * 8, X);
+  fe_store(jb.oy + i * 8, Y);
+  if (jb.oinf) jb.oinf[i] = inf ? 1 : 0;
+}
+
+hipError_t launch_fold_generators2(int curve, const FoldJob& j0, const FoldJob& j1, size_t h, hipStream_t st) {
+  if (h == 0) return hipSuccess;
+  unsigned blocks = (unsigned)((h + 127) / 128) * (j1.lx ? 2u : 1u);
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_fold_generators<C>, dim3(blocks), dim3(128), 0, st, j0, j1, h));
+  return hipGetLastError();
 }
 
 hipError_t launch_fold_generators(int curve, const u32* lx, const u32* ly, const uint8_t* linf,
                                   const u32* rx, const u32* ry, const uint8_t* rinf, size_t h,
                                   FeArg x_canon, FeArg y_canon, u32* ox, u32* oy, uint8_t* oinf,
                                   hipStream_t st) {
-  if (h == 0) return hipSuccess;
-  unsigned blocks = (unsigned)((h + 127) / 128);
-  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_fold_generators<C>, dim3(blocks), dim3(128), 0, st, lx,
-                                           ly, linf, rx, ry, rinf, h, x_canon, y_canon, ox, oy, oinf));
-  return hipGetLastError();
+  FoldJob j{lx, ly, linf, rx, ry, rinf, ox, oy, oinf, x_canon, y_canon};
+  return launch_fold_generators2(curve, j, FoldJob{}, h, st);
 }
 
 // out[i] = s[i] * P[i]  (src/range/aggregate.rs:148-153).  Per-point scalars, so

@@ -205,16 +205,30 @@ BP_DEV Fe fe_to_mont(const Fe& a) {
 }
 
 // a^(p-2): Fermat inverse; 0 maps to 0 (the convention of ark-ff's
-// batch_inversion, which leaves zeros untouched).
+// batch_inversion, which leaves zeros untouched).  Left-to-right sliding window of
+// width 3 over the constant exponent: 255 squarings + ~64 multiplies.
 template <class F>
 __host__ __device__ __noinline__ Fe fe_inv(const Fe& a) {
+  Fe a2 = fe_sqr<F>(a);
+  Fe t1 = a, t3 = fe_mul<F>(a, a2), t5 = fe_mul<F>(t3, a2), t7 = fe_mul<F>(t5, a2);
   Fe r = fe_one<F>();
-  for (int i = 7; i >= 0; i--) {
-    uint32_t w = F::pm2(i);
-    for (int b = 31; b >= 0; b--) {
+  int i = 255;
+  while (i >= 0) {
+    if (!((F::pm2(i >> 5) >> (i & 31)) & 1)) {
       r = fe_sqr<F>(r);
-      if ((w >> b) & 1) r = fe_mul<F>(r, a);
+      i--;
+      continue;
     }
+    int j = i - 2 < 0 ? 0 : i - 2;
+    while (!((F::pm2(j >> 5) >> (j & 31)) & 1)) j++;  // window [i..j] ends in a set bit
+    uint32_t v = 0;
+    for (int k = i; k >= j; k--) {
+      r = fe_sqr<F>(r);
+      v = (v << 1) | ((F::pm2(k >> 5) >> (k & 31)) & 1);
+    }
+    Fe m = fe_select(v == 1, t1, fe_select(v == 3, t3, fe_select(v == 5, t5, t7)));
+    r = fe_mul<F>(r, m);
+    i = j - 1;
   }
   return r;
 }

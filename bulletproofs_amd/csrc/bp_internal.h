@@ -46,6 +46,17 @@ hipError_t launch_fold_generators(int curve, const u32* lx, const u32* ly, const
                                   const u32* rx, const u32* ry, const uint8_t* rinf, size_t h,
                                   FeArg x_canon, FeArg y_canon, u32* ox, u32* oy, uint8_t* oinf,
                                   hipStream_t st);
+struct FoldJob {
+  const u32 *lx = nullptr, *ly = nullptr;
+  const uint8_t* linf = nullptr;
+  const u32 *rx = nullptr, *ry = nullptr;
+  const uint8_t* rinf = nullptr;
+  u32 *ox = nullptr, *oy = nullptr;
+  uint8_t* oinf = nullptr;
+  FeArg x{}, y{};  // canonical integers
+};
+// two independent folds of the same length in one launch (j1.lx == nullptr: one fold)
+hipError_t launch_fold_generators2(int curve, const FoldJob& j0, const FoldJob& j1, size_t h, hipStream_t st);
 // s: Montgomery-form scalars, one per point
 hipError_t launch_scale_points(int curve, const u32* px, const u32* py, const uint8_t* pinf,
                                const u32* s, size_t n, u32* ox, u32* oy, uint8_t* oinf,
