@@ -19,7 +19,7 @@ enum Slot {
   S_IN0, S_IN1, S_IN2, S_IN3, S_IN4, S_IN5, S_IN6,
   S_OUT0, S_OUT1, S_OUT2,
   S_KEYS_A, S_KEYS_B, S_VALS_A, S_VALS_B, S_SORT_TMP, S_BSTART, S_BEND, S_BUCKETS, S_SEGS,
-  S_WINDOWS, S_TABLE, S_SMALL, S_NCH, S_CHOFF, S_SCAN_TMP, S_CHUNK_SUMS, S_HEAVY, S_CKEY_A, S_CKEY_B, S_CVAL_A, S_CVAL_B, S_DESC_B, S_DESC_S, S_CSORT_TMP, S_SEG_GROUPS, S_COUNT
+  S_WINDOWS, S_TABLE, S_SMALL, S_NCH, S_CHOFF, S_SCAN_TMP, S_CHUNK_SUMS, S_HEAVY, S_CKEY_A, S_CKEY_B, S_CVAL_A, S_CVAL_B, S_DESC_B, S_DESC_S, S_CSORT_TMP, S_SEG_GROUPS, S_PACKED, S_COUNT
 };
 
 struct DevBuf {
@@ -168,6 +168,7 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
   if (e != hipSuccess) return fail(ctx, BP_E_ARG, "msm plan (n too large?)", e);
   MsmWorkspace ws{};
   void* p;
+  CHK(reserve(ctx, S_PACKED, plan->packed_bytes, &p)); ws.packed = (u32*)p;
   CHK(reserve(ctx, S_KEYS_A, plan->keys_bytes, &p)); ws.keys_a = (u32*)p;
   CHK(reserve(ctx, S_KEYS_B, plan->keys_bytes, &p)); ws.keys_b = (u32*)p;
   CHK(reserve(ctx, S_VALS_A, plan->keys_bytes, &p)); ws.vals_a = (u32*)p;

@@ -80,7 +80,7 @@ struct MsmPlan {
   size_t n_total; // points over both parts
   size_t entries; // W * n_total
   // workspace sizes in bytes
-  size_t keys_bytes, sort_tmp_bytes, bounds_bytes, bucket_bytes, seg_bytes, seg_group_bytes, win_bytes;
+  size_t keys_bytes, sort_tmp_bytes, bounds_bytes, bucket_bytes, seg_bytes, seg_group_bytes, win_bytes, packed_bytes;
   size_t scan_tmp_bytes, nch_bytes, chunk_sum_bytes, cdesc_bytes, csort_tmp_bytes;
   u32 chunk;      // max sorted entries per accumulation chunk
   size_t nc_cap;  // upper bound on the number of chunks
@@ -92,6 +92,7 @@ int msm_choose_window(size_t n);
 hipError_t msm_make_plan(int curve, size_t n_total, int c_override, MsmPlan* plan);
 
 struct MsmWorkspace {
+  u32* packed;        // points as x|y pairs, 16 u32 each
   u32* keys_a;
   u32* keys_b;
   u32* vals_a;

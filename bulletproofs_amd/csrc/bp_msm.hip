@@ -80,6 +80,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, MsmPlan* pla
   p.seg_bytes = (size_t)p.n_windows * p.n_segs * 128;
   p.seg_group_bytes = (size_t)p.n_windows * (p.n_segs / 1024 + 1) * 128;
   p.win_bytes = (size_t)p.n_windows * 128;
+  p.packed_bytes = (n_total ? n_total : 1) * 64;
   size_t tmp = 0;
   u32 max_key = (u32)nbt;
   hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
@@ -114,11 +115,22 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
                                                 size_t n0, const u32* __restrict__ s1,
                                                 const uint8_t* __restrict__ inf1, size_t n1, int c,
                                                 int n_windows, u32 n_buckets, u32* __restrict__ keys,
-                                                u32* __restrict__ vals) {
+                                                u32* __restrict__ vals, const u32* __restrict__ x0,
+                                                const u32* __restrict__ y0, const u32* __restrict__ x1,
+                                                const u32* __restrict__ y1, u32* __restrict__ packed) {
   using Fr = typename C::Fr;
   size_t n = n0 + n1;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  // x and y of a point side by side (64 contiguous bytes): the accumulation kernel
+  // gathers points in bucket order, and one 64-byte piece costs half the memory
+  // transactions of two 32-byte pieces from separate planes
+  {
+    const u32* px = i < n0 ? x0 + i * 8 : x1 + (i - n0) * 8;
+    const u32* py = i < n0 ? y0 + i * 8 : y1 + (i - n0) * 8;
+    fe_store(packed + i * 16, fe_load(px));
+    fe_store(packed + i * 16 + 8, fe_load(py));
+  }
   const u32* sp = i < n0 ? s0 + i * 8 : s1 + (i - n0) * 8;
   bool is_inf = i < n0 ? (inf0 && inf0[i]) : (inf1 && inf1[i - n0]);
   Fe k = fe_from_mont<Fr>(fe_load(sp));
@@ -260,9 +272,7 @@ __global__ __launch_bounds__(256) void k_chunk_desc(const u32* __restrict__ star
 }
 
 template <class C>
-__global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ x0, const u32* __restrict__ y0,
-                                                    size_t n0, const u32* __restrict__ x1,
-                                                    const u32* __restrict__ y1,
+__global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ packed,
                                                     const u32* __restrict__ vals,
                                                     const u32* __restrict__ ckey,
                                                     const u32* __restrict__ cval,
@@ -283,10 +293,8 @@ __global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ x0, 
   for (u32 p = s; p < e; p++) {
     u32 v = vals[p];
     size_t idx = v & 0x7fffffffu;
-    const u32* px = idx < n0 ? x0 + idx * 8 : x1 + (idx - n0) * 8;
-    const u32* py = idx < n0 ? y0 + idx * 8 : y1 + (idx - n0) * 8;
-    Fe qx = fe_load(px);
-    Fe qy = fe_load(py);
+    Fe qx = fe_load(packed + idx * 16);
+    Fe qy = fe_load(packed + idx * 16 + 8);
     if (v >> 31) qy = fe_neg<F>(qy);
     xyzz_madd<F>(acc, qx, qy);
   }
@@ -452,7 +460,8 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPla
   }
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_digits<C>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                            st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, plan.c,
-                                           plan.n_windows, plan.n_buckets, ws.keys_a, ws.vals_a));
+                                           plan.n_windows, plan.n_buckets, ws.keys_a, ws.vals_a, p0.x, p0.y, p1.x, p1.y,
+                                           ws.packed));
   if ((e = hipGetLastError()) != hipSuccess) return e;
   size_t tmp = plan.sort_tmp_bytes;
   e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
@@ -480,7 +489,7 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPla
   if (e != hipSuccess) return e;
   if (ev_acc0 && (e = hipEventRecord(ev_acc0, st)) != hipSuccess) return e;
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_chunk_sums<C>, dim3((unsigned)((plan.nc_cap + 127) / 128)), dim3(128),
-                                           0, st, p0.x, p0.y, p0.n, p1.x, p1.y, ws.vals_b, ws.ckey_b, ws.cval_b,
+                                           0, st, ws.packed, ws.vals_b, ws.ckey_b, ws.cval_b,
                                            ws.desc_b, ws.desc_s, ws.nch, nbt, plan.chunk, plan.nc_cap, ws.buckets,
                                            ws.chunk_sums));
   if ((e = hipGetLastError()) != hipSuccess) return e;
