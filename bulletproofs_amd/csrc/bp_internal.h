@@ -76,6 +76,7 @@ struct MsmPart {
 struct MsmPlan {
   int c;          // window bits
   int n_windows;  // W
+  int wshift;     // bit position of the window number inside a sorted value word
   u32 n_buckets;  // per window = 2^(c-1)
   size_t n_total; // points over both parts
   size_t entries; // W * n_total

@@ -82,7 +82,12 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, MsmPlan* pla
   p.win_bytes = (size_t)p.n_windows * 128;
   p.packed_bytes = (n_total ? n_total : 1) * 64;
   size_t tmp = 0;
-  u32 max_key = (u32)nbt;
+  // value word: sign (bit 31) | window | point index
+  int wbits = 0;
+  while ((1 << wbits) < p.n_windows) wbits++;
+  p.wshift = 31 - wbits;
+  if (n_total >= ((size_t)1 << p.wshift)) return hipErrorInvalidValue;
+  u32 max_key = p.n_buckets;
   hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
       nullptr, tmp, nullptr, nullptr, nullptr, nullptr, p.entries ? p.entries : 1, 0,
       key_bits_for(max_key), 0, false);
@@ -114,8 +119,9 @@ template <class C>
 __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, const uint8_t* __restrict__ inf0,
                                                 size_t n0, const u32* __restrict__ s1,
                                                 const uint8_t* __restrict__ inf1, size_t n1, int c,
-                                                int n_windows, u32 n_buckets, u32* __restrict__ keys,
-                                                u32* __restrict__ vals, const u32* __restrict__ x0,
+                                                int n_windows, u32 n_buckets, int wshift,
+                                                u32* __restrict__ keys, u32* __restrict__ vals,
+                                                const u32* __restrict__ x0,
                                                 const u32* __restrict__ y0, const u32* __restrict__ x1,
                                                 const u32* __restrict__ y1, u32* __restrict__ packed) {
   using Fr = typename C::Fr;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
       flip = 0x80000000u;
     }
   }
-  const u32 invalid = (u32)n_windows * n_buckets;
+  const u32 invalid = n_buckets;  // sorts behind every bucket
   const u32 half = 1u << (c - 1);
   const u32 mask = (1u << c) - 1;
   u32 carry = 0;
@@ -175,12 +181,12 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
     if (v > half) {
       carry = 1;
       u32 mag = (1u << c) - v;  // |v - 2^c|
-      key = mag ? (u32)w * n_buckets + (mag - 1) : invalid;  // v == 2^c: digit 0, carry 1
-      val = ((u32)i | 0x80000000u) ^ flip;
+      key = mag ? mag - 1 : invalid;  // v == 2^c: digit 0, carry 1
+      val = ((u32)i | ((u32)w << wshift) | 0x80000000u) ^ flip;
     } else {
       carry = 0;
-      key = v ? (u32)w * n_buckets + (v - 1) : invalid;
-      val = (u32)i ^ flip;
+      key = v ? v - 1 : invalid;
+      val = ((u32)i | ((u32)w << wshift)) ^ flip;
     }
     if (is_inf) key = invalid;
     keys[(size_t)w * n + i] = key;
@@ -189,13 +195,21 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
 }
 
 // ---- 3. bucket bounds ---------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ keys, size_t entries,
+__global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ keys, const u32* __restrict__ vals,
+                                                size_t entries, u32 n_buckets, int wshift,
                                                 u32* __restrict__ start, u32* __restrict__ end) {
+  // The sort key is the bucket number alone; the input was window-major and the sort
+  // is stable, so equal keys stay in window order: runs of equal (bucket, window) are
+  // contiguous.  start/end are indexed window-major (w * n_buckets + bucket).
   size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= entries) return;
   u32 k = keys[p];
-  if (p == 0 || keys[p - 1] != k) start[k] = (u32)p;
-  if (p + 1 == entries || keys[p + 1] != k) end[k] = (u32)(p + 1);
+  if (k >= n_buckets) return;  // zero digit / identity base
+  const u32 wmask = 0x7fffffffu >> wshift << wshift;
+  u32 w = vals[p] & wmask;
+  u32 b = (w >> wshift) * n_buckets + k;
+  if (p == 0 || keys[p - 1] != k || (vals[p - 1] & wmask) != w) start[b] = (u32)p;
+  if (p + 1 == entries || keys[p + 1] != k || (vals[p + 1] & wmask) != w) end[b] = (u32)(p + 1);
 }
 
 // ---- 4. bucket accumulation -----------------------------------------------------
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ pack
                                                     const u32* __restrict__ desc_b,
                                                     const u32* __restrict__ desc_s,
                                                     const u32* __restrict__ nch, size_t nbt, u32 chunk,
-                                                    size_t nc_cap, u32* __restrict__ buckets,
+                                                    size_t nc_cap, u32 idx_mask, u32* __restrict__ buckets,
                                                     u32* __restrict__ chunk_sums) {
   using F = typename C::Fq;
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ pack
   Xyzz acc = xyzz_identity<F>();
   for (u32 p = s; p < e; p++) {
     u32 v = vals[p];
-    size_t idx = v & 0x7fffffffu;
+    size_t idx = v & idx_mask;
     Fe qx = fe_load(packed + idx * 16);
     Fe qy = fe_load(packed + idx * 16 + 8);
     if (v >> 31) qy = fe_neg<F>(qy);
@@ -460,18 +474,18 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPla
   }
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_digits<C>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                            st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, plan.c,
-                                           plan.n_windows, plan.n_buckets, ws.keys_a, ws.vals_a, p0.x, p0.y, p1.x, p1.y,
+                                           plan.n_windows, plan.n_buckets, plan.wshift, ws.keys_a, ws.vals_a, p0.x, p0.y, p1.x, p1.y,
                                            ws.packed));
   if ((e = hipGetLastError()) != hipSuccess) return e;
   size_t tmp = plan.sort_tmp_bytes;
   e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
       ws.sort_tmp, tmp, ws.keys_a, ws.keys_b, ws.vals_a, ws.vals_b, plan.entries, 0,
-      key_bits_for((u32)nbt), st, false);
+      key_bits_for(plan.n_buckets), st, false);
   if (e != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.bucket_start, 0, plan.bounds_bytes, st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.bucket_end, 0, plan.bounds_bytes, st)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_bounds, dim3((unsigned)((plan.entries + 255) / 256)), dim3(256), 0, st, ws.keys_b,
-                     plan.entries, ws.bucket_start, ws.bucket_end);
+                     ws.vals_b, plan.entries, plan.n_buckets, plan.wshift, ws.bucket_start, ws.bucket_end);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   hipLaunchKernelGGL(k_chunk_counts, dim3((unsigned)((nbt + 256) / 256)), dim3(256), 0, st, ws.bucket_start,
                      ws.bucket_end, nbt, plan.chunk, ws.nch);
@@ -490,7 +504,7 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPla
   if (ev_acc0 && (e = hipEventRecord(ev_acc0, st)) != hipSuccess) return e;
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_chunk_sums<C>, dim3((unsigned)((plan.nc_cap + 127) / 128)), dim3(128),
                                            0, st, ws.packed, ws.vals_b, ws.ckey_b, ws.cval_b,
-                                           ws.desc_b, ws.desc_s, ws.nch, nbt, plan.chunk, plan.nc_cap, ws.buckets,
+                                           ws.desc_b, ws.desc_s, ws.nch, nbt, plan.chunk, plan.nc_cap, (1u << plan.wshift) - 1u, ws.buckets,
                                            ws.chunk_sums));
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;
