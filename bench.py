@@ -123,8 +123,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # BP_BENCH_FORCE_DIST=1 runs the collective path even with one rank (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("BP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n = 1 << args.log2n
     ctx = bp.Context(local_rank)
@@ -134,17 +138,17 @@ def main():
     dx, dy, dk = to_dev(px), to_dev(py), to_dev(ks)
     from bulletproofs_amd.sharded import ShardedMsm
 
-    sharded = ShardedMsm(ctx, bp.SECP256K1, dist=dist if world > 1 else None)
+    sharded = ShardedMsm(ctx, bp.SECP256K1, dist=dist if use_dist else None)
     win = sharded.win
 
     def step():
-        if world == 1:
+        if not use_dist:
             return ctx.msm_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n)
         # per-rank window sums -> one RCCL all_gather -> window-wise combine on every GPU
         return sharded.msm(dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,7 +163,7 @@ def main():
         dev_ms.append(ctx.last_kernel_ms(1))
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -210,7 +214,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n)
         assert res is not None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -141,3 +141,125 @@ int bph_ipa_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_t
 }
 
 }  // extern "C"
+
+// ---- aggregated range proof round trip ------------------------------------------------
+#include <chrono>
+
+#include "bp_host_range.hpp"
+
+namespace {
+
+template <class Fr>
+struct SeededRandom : RandomSource {
+  uint64_t st;
+  explicit SeededRandom(uint64_t seed) : st(seed) {}
+  uint64_t next() {
+    st += 0x9E3779B97F4A7C15ull;
+    uint64_t z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  Scalar scalar() override {
+    for (;;) {
+      HFe v;
+      for (int k = 0; k < 4; k++) v.v[k] = next();
+      if (!h_geq_mod<Fr>(v)) {
+        Scalar c;
+        memcpy(c.l, v.v, 32);
+        return ScalarOps<Fr>::to_mont(c);
+      }
+    }
+  }
+};
+
+template <class Fq, class Fr, int CURVE>
+int range_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx, const uint64_t* hy,
+                    const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma, size_t m, unsigned n_bits,
+                    uint64_t seed_rand, uint64_t seed_chal, int tamper, int reps, uint64_t* out_points,
+                    uint64_t* out_scalars, uint64_t* out_lr, double* prove_ms, double* verify_ms, int* ok) {
+  using R = RangeAggregate<Fq, Fr, CURVE>;
+  using PO = PointOps<Fq, Fr>;
+  size_t n = (size_t)n_bits * m;
+  typename R::Crs crs;
+  crs.ipa.gs = unpack(gx, gy, nullptr, n);
+  crs.ipa.hs = unpack(hx, hy, nullptr, n);
+  auto pt = [&](int k) { Affine a; memcpy(a.x, ugh_xy + 8 * k, 32); memcpy(a.y, ugh_xy + 8 * k + 4, 32); a.inf = 0; return a; };
+  crs.ipa.u = pt(0); crs.g = pt(1); crs.h = pt(2);
+  R::register_bases(ctx, crs, n);
+  std::vector<uint64_t> vals(values, values + m);
+  std::vector<Scalar> gam = unpack_s(gamma, m);
+  // statement: V_j = v_j g + gamma_j h  (src/range/types.rs:167-176)
+  std::vector<Projective> vcom(m);
+  for (size_t j = 0; j < m; j++)
+    vcom[j] = PO::lower(hx_add<Fq>(PO::mul(PO::lift(crs.g), R::from_u64(vals[j])), PO::mul(PO::lift(crs.h), gam[j])));
+  RangeProof proof;
+  double tp = 0, tv = 0;
+  *ok = 1;
+  try {
+    for (int r = 0; r < reps; r++) {
+      SeededTranscript<Fr> t1(seed_chal);
+      SeededRandom<Fr> rng(seed_rand);
+      auto a = std::chrono::steady_clock::now();
+      proof = R::prove(ctx, crs, vals, gam, n_bits, t1, rng);
+      auto b = std::chrono::steady_clock::now();
+      RangeProof check_proof = proof;
+      if (tamper) check_proof.t_hat = ScalarOps<Fr>::add(check_proof.t_hat, ScalarOps<Fr>::one());
+      SeededTranscript<Fr> t2(seed_chal);
+      SeededRandom<Fr> vrng(seed_rand ^ 0x5EEDull);
+      auto c = std::chrono::steady_clock::now();
+      auto msm = R::verify_aux(ctx, crs, vcom, n_bits, check_proof, t2, vrng);
+      bool good = is_zero(msm.execute());  // src/range/aggregate.rs:294-299
+      auto d = std::chrono::steady_clock::now();
+      if (!good) *ok = 0;
+      tp += std::chrono::duration<double, std::milli>(b - a).count();
+      tv += std::chrono::duration<double, std::milli>(d - c).count();
+    }
+  } catch (...) {
+    bp_bases_free(crs.gh);
+    throw;
+  }
+  bp_bases_free(crs.gh);
+  *prove_ms = tp / reps;
+  *verify_ms = tv / reps;
+  memcpy(out_points, proof.a.xyz, 96); memcpy(out_points + 12, proof.s.xyz, 96);
+  memcpy(out_points + 24, proof.tt1.xyz, 96); memcpy(out_points + 36, proof.tt2.xyz, 96);
+  memcpy(out_scalars, proof.tao_x.l, 32); memcpy(out_scalars + 4, proof.mu.l, 32); memcpy(out_scalars + 8, proof.t_hat.l, 32);
+  memcpy(out_scalars + 12, proof.ipa.a.l, 32); memcpy(out_scalars + 16, proof.ipa.b.l, 32);
+  for (size_t j = 0; j < proof.ipa.L.size(); j++) {
+    memcpy(out_lr + 24 * j, proof.ipa.L[j].xyz, 96);
+    memcpy(out_lr + 24 * j + 12, proof.ipa.R[j].xyz, 96);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Aggregated range proof over m values of n_bits bits (N = m*n_bits a power of two):
+// prove, then verify, `reps` times with identical seeds; averages the wall time of
+// each phase.  ugh_xy = affine u, g, h (3 x 8 u64).  Outputs of the last proof:
+// out_points = A, S, T1, T2 (4 x 12 u64); out_scalars = tao_x, mu, t_hat, a, b
+// (5 x 4 u64); out_lr = log2(N) x (L, R) (24 u64 each).
+int bph_range_agg_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx,
+                            const uint64_t* hy, const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma,
+                            size_t m, unsigned n_bits, uint64_t seed_rand, uint64_t seed_chal, int tamper, int reps,
+                            uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_lr, double* prove_ms,
+                            double* verify_ms, int* ok) {
+  try {
+    if (curve == BP_SECP256K1)
+      return range_roundtrip<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(ctx, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits,
+                                                                    seed_rand, seed_chal, tamper, reps, out_points,
+                                                                    out_scalars, out_lr, prove_ms, verify_ms, ok);
+    if (curve == BP_VESTA)
+      return range_roundtrip<VestaFq, VestaFr, BP_VESTA>(ctx, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits, seed_rand,
+                                                        seed_chal, tamper, reps, out_points, out_scalars, out_lr, prove_ms,
+                                                        verify_ms, ok);
+    return BP_E_CURVE;
+  } catch (const std::exception&) {
+    return BP_E_HIP;
+  }
+}
+
+}  // extern "C"

@@ -56,3 +56,34 @@ def ipa_roundtrip(ctx: Context, curve, gs, hs, u_xy, a, b, n_proofs=1, seed=1, t
         raise RuntimeError(f"bph_ipa_roundtrip rc={rc}")
     return dict(L=out_l[:k], R=out_r[:k], a=out_ab[:4], b=out_ab[4:], P=out_p, single_ok=bool(ok1.value),
                 batch_ok=bool(okb.value))
+
+
+hlib.bph_range_agg_roundtrip.restype = ci
+hlib.bph_range_agg_roundtrip.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint64, C.c_uint64, ci, ci,
+                                         vp, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]
+
+
+def range_aggregate_roundtrip(ctx: Context, curve, gs, hs, ugh_xy, values, gamma, n_bits, seed_rand=1, seed_chal=2,
+                              tamper=False, reps=1):
+    """aggregated range proof (src/range/aggregate.rs): prove + verify through the GPU path.
+    ugh_xy: (3, 8) uint64 = affine u, g, h.  values: m integers < 2^n_bits."""
+    gx, gy, _ = _pts(gs)
+    hx, hy, _ = _pts(hs)
+    values = np.ascontiguousarray(values, dtype=np.uint64)
+    gamma = _f(gamma)
+    m = values.shape[0]
+    n = m * n_bits
+    assert n & (n - 1) == 0 and gx.shape[0] >= n and hx.shape[0] >= n
+    k = n.bit_length() - 1
+    ugh_xy = np.ascontiguousarray(ugh_xy, dtype=np.uint64).reshape(24)
+    pts = np.zeros((4, 12), dtype=np.uint64)
+    sc = np.zeros((5, 4), dtype=np.uint64)
+    lr = np.zeros((max(k, 1), 24), dtype=np.uint64)
+    tp, tv, ok = C.c_double(), C.c_double(), ci()
+    rc = hlib.bph_range_agg_roundtrip(ctx.h, curve, _p(gx), _p(gy), _p(hx), _p(hy), _p(ugh_xy), _p(values), _p(gamma), m,
+                                      n_bits, seed_rand, seed_chal, int(tamper), reps, _p(pts), _p(sc), _p(lr),
+                                      C.byref(tp), C.byref(tv), C.byref(ok))
+    if rc:
+        raise RuntimeError(f"bph_range_agg_roundtrip rc={rc}")
+    return dict(A=pts[0], S=pts[1], TT1=pts[2], TT2=pts[3], tao_x=sc[0], mu=sc[1], t_hat=sc[2], a=sc[3], b=sc[4],
+                L=lr[:k, :12], R=lr[:k, 12:], prove_ms=tp.value, verify_ms=tv.value, ok=bool(ok.value))

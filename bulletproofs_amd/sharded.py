@@ -29,8 +29,9 @@ class ShardedMsm:
 
         self.torch = torch
         self.ctx, self.curve, self.dist = ctx, curve, dist
-        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.collective = dist is not None and dist.is_initialized()
+        self.world = dist.get_world_size() if self.collective else 1
+        self.rank = dist.get_rank() if self.collective else 0
         self.win = torch.zeros(MAX_WINDOWS * WINDOW_U64, dtype=torch.int64, device=device)
         self.gathered = torch.zeros((self.world, MAX_WINDOWS * WINDOW_U64), dtype=torch.int64, device=device)
         self._local = local_windows or self._local_dev
@@ -45,7 +46,7 @@ class ShardedMsm:
 
     def msm(self, d_x, d_y, d_inf, d_s, n_local):
         nw, cb = self._local(d_x, d_y, d_inf, d_s, n_local, self.win)
-        if self.world > 1:
+        if self.collective:
             self.dist.all_gather_into_tensor(self.gathered.view(-1), self.win)
             if self.gathered.is_cuda:
                 self.torch.cuda.current_stream().synchronize()

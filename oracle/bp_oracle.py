@@ -561,3 +561,67 @@ def ipa_verify_scalars(challenges, a, b, c: Curve):
     ss = s_vector(challenges, c.n)
     ss_inv = batch_inversion(ss, c.n)
     return scale(ss, a, c.n), scale(ss_inv, b, c.n)
+
+
+# ---------------------------------------------------------------------------
+# Aggregated range proof, prover side (src/range/aggregate.rs:23-170) with seeded
+# randomness and challenges: the caller of the hot path for BASELINE config 4.
+# ---------------------------------------------------------------------------
+
+
+def range_aggregate_prove(c: Curve, gs, hs, u, g, h, values, gammas, n_bits, rand_seed, chal_seed):
+    """Returns every prover message.  Randomness: one SplitMix64 stream (alpha, rho,
+    s_L, s_R, tau1, tau2 in the reference's order); challenge number j is the first
+    field element of SplitMix64(chal_seed + j)."""
+    mod = c.n
+    m = len(values)
+    n = n_bits * m
+    rnd = SplitMix64(rand_seed)
+    counter = [0]
+
+    def chal():
+        v = SplitMix64(chal_seed + counter[0]).field(mod)
+        counter[0] += 1
+        return v
+
+    gs, hs = list(gs[:n]), list(hs[:n])
+    a_l = [(v >> i) & 1 for v in values for i in range(n_bits)]          # :50-58
+    a_r = [(b - 1) % mod for b in a_l]                                     # :60-64
+    alpha, rho = rnd.field(mod), rnd.field(mod)                            # :66-67
+    s_l = [rnd.field(mod) for _ in range(n)]                               # :68-70
+    s_r = [rnd.field(mod) for _ in range(n)]                               # :71-73
+    msm = msm_pippenger if n > 16 else msm_naive
+    A = add(scalar_mul(alpha, h, c), msm(gs + hs, a_l + a_r, c), c)        # :81
+    S = add(scalar_mul(rho, h, c), msm(gs + hs, s_l + s_r, c), c)          # :82
+    y, z = chal(), chal()                                                  # :86
+    y_vec = powers(y, n, mod)
+    l0 = [(a - z) % mod for a in a_l]                                      # :93-101
+    zz = z * z % mod
+    r0, r1 = [], []
+    for j in range(m):                                                     # :103-119
+        zp = zz * pow(z, j, mod) % mod
+        for i in range(n_bits):
+            k = j * n_bits + i
+            r0.append((y_vec[k] * ((a_r[k] + z) % mod) + zp * pow(2, i, mod)) % mod)
+            r1.append(y_vec[k] * s_r[k] % mod)
+    tao1, tao2 = rnd.field(mod), rnd.field(mod)                            # :121-122
+    t1 = (inner_product(l0, r1, mod) + inner_product(s_l, r0, mod)) % mod  # src/range/types.rs:98-117
+    t2 = inner_product(s_l, r1, mod)
+    TT1 = add(scalar_mul(t1, g, c), scalar_mul(tao1, h, c), c)             # :126
+    TT2 = add(scalar_mul(t2, g, c), scalar_mul(tao2, h, c), c)             # :127
+    x = chal()                                                             # :133
+    sigma = sum(zz * pow(z, j, mod) * gammas[j] for j in range(m)) % mod   # :136-139
+    tao_x = (tao1 * x + tao2 * x * x + sigma) % mod                        # :140
+    mu = (alpha + rho * x) % mod                                           # :142
+    l = [(a + b * x) % mod for a, b in zip(l0, s_l)]                       # :143
+    r = [(a + b * x) % mod for a, b in zip(r0, r1)]                        # :144
+    t_hat = inner_product(l, r, mod)
+    hs_p = scale_points(hs, hs_prime_scalars(n, y, mod), c)                # :148-153
+    xe = chal()                                                            # src/ipa/extended.rs:24
+    u2 = scalar_mul(xe, u, c)                                              # :32
+    k = n.bit_length() - 1
+    chs = [chal() for _ in range(k)]
+    rounds, (gf, hf, af, bf) = ipa_prove(BULLETPROOF, gs, hs_p, l, r, chs, c, msm)
+    Ls = [add(rd["L"], scalar_mul(rd["cL"], u2, c), c) for rd in rounds]   # src/ipa/mod.rs:43
+    Rs = [add(rd["R"], scalar_mul(rd["cR"], u2, c), c) for rd in rounds]
+    return dict(A=A, S=S, TT1=TT1, TT2=TT2, tao_x=tao_x, mu=mu, t_hat=t_hat, L=Ls, R=Rs, a=af[0], b=bf[0])
