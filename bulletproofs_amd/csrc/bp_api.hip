@@ -51,13 +51,25 @@ struct bp_bases {
   uint8_t* inf;
 };
 
+// The prover never folds the generator vectors.  It keeps the vectors it was given and, per
+// generator, the product of the challenges that folding would have multiplied it by (cg, ch);
+// the cross terms L, R of a round are then MSMs over the original generators with scalars
+// cg[k]*a[..] / ch[k]*b[..].  Folded generators exist only when bp_ipa_read asks for them.
 struct bp_ipa {
-  bp_ctx* ctx;
-  int curve;
-  int variant;
-  size_t n;
-  u32 *gx, *gy, *hx, *hy, *a, *b;
-  uint8_t *ginf, *hinf;
+  bp_ctx* ctx = nullptr;
+  int curve = 0;
+  int variant = 0;
+  size_t n = 0;   // current length of a, b
+  size_t n0 = 0;  // length at bp_ipa_begin
+  u32 *gx = nullptr, *gy = nullptr, *hx = nullptr, *hy = nullptr;  // n0 points each, as given
+  uint8_t *ginf = nullptr, *hinf = nullptr;
+  u32 *a = nullptr, *b = nullptr;    // folded in place
+  u32 *cg = nullptr, *ch = nullptr;  // n0 coefficients each
+  u32 *eg = nullptr, *eh = nullptr;  // n0 cross-term scalars each
+  // folded generators, materialised on demand (n0/2 points each)
+  u32 *fgx = nullptr, *fgy = nullptr, *fhx = nullptr, *fhy = nullptr;
+  uint8_t *fginf = nullptr, *fhinf = nullptr;
+  std::vector<FeArg> x_canon, xinv_canon;  // challenges so far, canonical integers
 };
 
 namespace {
@@ -162,9 +174,9 @@ void finish_windows(int curve, const uint64_t* win, int n_windows, int c, uint64
 
 // device phase of an MSM: leaves plan->n_windows XYZZ window sums in S_WINDOWS
 int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, MsmPlan* plan,
-               u32** d_windows) {
+               u32** d_windows, int groups = 1) {
   size_t n = p0.n + p1.n;
-  hipError_t e = msm_make_plan(curve, n, ctx->c_override, plan);
+  hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan);
   if (e != hipSuccess) return fail(ctx, BP_E_ARG, "msm plan (n too large?)", e);
   MsmWorkspace ws{};
   void* p;
@@ -695,7 +707,8 @@ void bp_ipa_free(bp_ipa* s) {
   if (!s) return;
   Guard g(s->ctx);
   (void)hipStreamSynchronize(s->ctx->stream);
-  void* ptrs[] = {s->gx, s->gy, s->ginf, s->hx, s->hy, s->hinf, s->a, s->b};
+  void* ptrs[] = {s->gx, s->gy, s->ginf, s->hx, s->hy, s->hinf, s->a, s->b, s->cg, s->ch, s->eg,
+                  s->eh, s->fgx, s->fgy, s->fginf, s->fhx, s->fhy, s->fhinf};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -712,11 +725,10 @@ int bp_ipa_begin(bp_ctx* ctx, int curve, int variant, const uint64_t* gx, const 
   Guard g(ctx);
   bp_ipa* s = new (std::nothrow) bp_ipa();
   if (!s) return fail(ctx, BP_E_OOM, "host allocation");
-  memset(s, 0, sizeof *s);
   s->ctx = ctx;
   s->curve = curve;
   s->variant = variant;
-  s->n = n;
+  s->n = s->n0 = n;
   bool has_h = variant == BP_IPA_BULLETPROOF;
   hipError_t e = hipSuccess;
   auto alloc = [&](void** p, size_t bytes) {
@@ -724,7 +736,13 @@ int bp_ipa_begin(bp_ctx* ctx, int curve, int variant, const uint64_t* gx, const 
   };
   alloc((void**)&s->gx, n * 32); alloc((void**)&s->gy, n * 32); alloc((void**)&s->ginf, n);
   alloc((void**)&s->a, n * 32); alloc((void**)&s->b, n * 32);
-  if (has_h) { alloc((void**)&s->hx, n * 32); alloc((void**)&s->hy, n * 32); alloc((void**)&s->hinf, n); }
+  alloc((void**)&s->cg, n * 32); alloc((void**)&s->eg, n * 32);
+  if (has_h) {
+    alloc((void**)&s->hx, n * 32); alloc((void**)&s->hy, n * 32); alloc((void**)&s->hinf, n);
+    alloc((void**)&s->ch, n * 32); alloc((void**)&s->eh, n * 32);
+  }
+  if (e == hipSuccess) e = launch_fill_one(curve, s->cg, n, ctx->stream);
+  if (e == hipSuccess && has_h) e = launch_fill_one(curve, s->ch, n, ctx->stream);
   auto put = [&](void* d, const void* h, size_t bytes) {
     if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream);
   };
@@ -753,25 +771,46 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
   bp_ctx* ctx = s->ctx;
   if (s->n < 2) return fail(ctx, BP_E_STATE, "bp_ipa_round_lr: vectors already folded to length 1");
   Guard g(ctx);
-  size_t h = s->n / 2;
+  const size_t h = s->n / 2, n0 = s->n0;
+  const bool has_h = s->variant == BP_IPA_BULLETPROOF;
   const u32 *a_lo = s->a, *a_hi = s->a + h * 8, *b_lo = s->b, *b_hi = s->b + h * 8;
-  const u32 *gx_lo = s->gx, *gx_hi = s->gx + h * 8, *gy_lo = s->gy, *gy_hi = s->gy + h * 8;
-  const uint8_t *gi_lo = s->ginf, *gi_hi = s->ginf + h;
-  MsmPart none{nullptr, nullptr, nullptr, nullptr, 0};
-  if (s->variant == BP_IPA_BULLETPROOF) {
-    const u32 *hx_lo = s->hx, *hx_hi = s->hx + h * 8, *hy_lo = s->hy, *hy_hi = s->hy + h * 8;
-    const uint8_t *hi_lo = s->hinf, *hi_hi = s->hinf + h;
-    // L: bases g_hi || h_lo, scalars a_lo || b_hi  (src/ipa/mod.rs:44-54)
-    CHK(msm_full(ctx, s->curve, MsmPart{gx_hi, gy_hi, gi_hi, a_lo, h}, MsmPart{hx_lo, hy_lo, hi_lo, b_hi, h}, l_xyz));
-    // R: bases g_lo || h_hi, scalars a_hi || b_lo  (src/ipa/mod.rs:60-70)
-    CHK(msm_full(ctx, s->curve, MsmPart{gx_lo, gy_lo, gi_lo, a_hi, h}, MsmPart{hx_hi, hy_hi, hi_hi, b_lo, h}, r_xyz));
-  } else {
-    // src/poly_commit/mod.rs:78,83
-    CHK(msm_full(ctx, s->curve, MsmPart{gx_hi, gy_hi, gi_hi, a_lo, h}, none, l_xyz));
-    CHK(msm_full(ctx, s->curve, MsmPart{gx_lo, gy_lo, gi_lo, a_hi, h}, none, r_xyz));
+  hipError_t e = launch_ipa_scalars(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, n0, h, s->eg, s->eh,
+                                    ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_scalars", e);
+  // One pass computes both cross terms: group 0 = L, group 1 = R.
+  //   L: G_hi with a_lo, H_lo with b_hi (src/ipa/mod.rs:44-54); R: G_lo with a_hi, H_hi with b_lo (:60-70)
+  //   poly-commit: L = <g_hi, a_lo>, R = <g_lo, a_hi> (src/poly_commit/mod.rs:78,83)
+  MsmPart pg{s->gx, s->gy, s->ginf, s->eg, n0};
+  pg.sel_half = h; pg.group_hi = 0; pg.group_lo = 1;
+  MsmPart ph{nullptr, nullptr, nullptr, nullptr, 0};
+  if (has_h) {
+    ph = MsmPart{s->hx, s->hy, s->hinf, s->eh, n0};
+    ph.sel_half = h; ph.group_lo = 0; ph.group_hi = 1;
   }
-  CHK(dot_dev(ctx, s->curve, a_lo, b_hi, h, c_l));
-  CHK(dot_dev(ctx, s->curve, a_hi, b_lo, h, c_r));
+  MsmPlan plan;
+  u32* d_win = nullptr;
+  CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2));
+  // c_l = <a_lo, b_hi>, c_r = <a_hi, b_lo> (src/ipa/mod.rs:42,58)
+  void* part;
+  CHK(reserve(ctx, S_SMALL, (size_t)2 * (kDotBlocks + 1) * 32, &part));
+  u32* part_l = (u32*)part;
+  u32* part_r = part_l + (size_t)(kDotBlocks + 1) * 8;
+  u32 *d_cl = part_l + (size_t)kDotBlocks * 8, *d_cr = part_r + (size_t)kDotBlocks * 8;
+  e = launch_inner_product(s->curve, a_lo, b_hi, h, part_l, d_cl, ctx->stream);
+  if (e == hipSuccess) e = launch_inner_product(s->curve, a_hi, b_lo, h, part_r, d_cr, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "inner_product", e);
+  CHK(reserve_pinned(ctx, plan.win_bytes + 64));
+  char* host = (char*)ctx->pinned;
+  HIPCHK(ctx, hipMemcpyAsync(host, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(host + plan.win_bytes, d_cl, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(host + plan.win_bytes + 32, d_cr, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  msm_collect_times(ctx, true);
+  const uint64_t* win = (const uint64_t*)host;
+  finish_windows(s->curve, win, plan.group_windows, plan.c, l_xyz);
+  finish_windows(s->curve, win + (size_t)plan.group_windows * 16, plan.group_windows, plan.c, r_xyz);
+  memcpy(c_l, host + plan.win_bytes, 32);
+  memcpy(c_r, host + plan.win_bytes + 32, 32);
   return BP_OK;
 }
 
@@ -784,26 +823,25 @@ int bp_ipa_round_fold(bp_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]) {
   FeArg xm = to_arg(x), xim = to_arg(x_inv);
   FeArg xc = to_canonical_fr(s->curve, x), xic = to_canonical_fr(s->curve, x_inv);
   hipError_t e;
+  // G' = x^-1*G_lo + x*G_hi (both variants: src/ipa/mod.rs:81, src/poly_commit/mod.rs:102) and
+  // H' = x*H_lo + x^-1*H_hi (src/ipa/mod.rs:82) become coefficient updates of the original
+  // generators: upper-half G entries and lower-half H entries gain x, the others x^-1.
+  const bool has_h = s->variant == BP_IPA_BULLETPROOF;
+  e = launch_ipa_coef_update(s->curve, s->cg, has_h ? s->ch : nullptr, s->n0, h, xm, xim, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_coef_update", e);
   // Outputs overwrite the low halves in place: output i reads only inputs i and i+h.
-  // G' = x^-1*G_lo + x*G_hi (both variants: src/ipa/mod.rs:81, src/poly_commit/mod.rs:102)
-  FoldJob jg{s->gx, s->gy, s->ginf, s->gx + h * 8, s->gy + h * 8, s->ginf + h, s->gx, s->gy, s->ginf, xic, xc};
-  if (s->variant == BP_IPA_BULLETPROOF) {
-    // H' = x*H_lo + x^-1*H_hi (src/ipa/mod.rs:82), same launch as the G fold
-    FoldJob jh{s->hx, s->hy, s->hinf, s->hx + h * 8, s->hy + h * 8, s->hinf + h, s->hx, s->hy, s->hinf, xc, xic};
-    e = launch_fold_generators2(s->curve, jg, jh, h, ctx->stream);
-    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_generators(G,H)", e);
+  if (has_h) {
     // a' = a_lo*x + a_hi*x^-1 ; b' = b_lo*x^-1 + b_hi*x (src/ipa/mod.rs:88-89)
     e = launch_fold_scalars(s->curve, s->a, s->a + h * 8, h, xm, xim, s->a, ctx->stream);
     if (e == hipSuccess) e = launch_fold_scalars(s->curve, s->b, s->b + h * 8, h, xim, xm, s->b, ctx->stream);
   } else {
-    e = launch_fold_generators2(s->curve, jg, FoldJob{}, h, ctx->stream);
-    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_generators(G)", e);
     // a' = a_hi*u^-1 + a_lo*u ; b' = b_lo*u^-1 + b_hi*u (src/poly_commit/mod.rs:96-97)
     e = launch_fold_scalars(s->curve, s->a + h * 8, s->a, h, xim, xm, s->a, ctx->stream);
     if (e == hipSuccess) e = launch_fold_scalars(s->curve, s->b, s->b + h * 8, h, xim, xm, s->b, ctx->stream);
   }
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_scalars", e);
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  s->x_canon.push_back(xc);
+  s->xinv_canon.push_back(xic);
   s->n = h;
   return BP_OK;
 }
@@ -813,13 +851,70 @@ int bp_ipa_read(bp_ipa* s, uint64_t* gx, uint64_t* gy, uint8_t* ginf, uint64_t* 
   if (!s) return BP_E_ARG;
   bp_ctx* ctx = s->ctx;
   Guard g(ctx);
-  size_t n = s->n;
+  const size_t n = s->n, n0 = s->n0;
+  const bool has_h = s->variant == BP_IPA_BULLETPROOF;
+  const bool want_g = gx || gy || ginf, want_h = hx || hy || hinf;
+  if (want_h && !has_h) return fail(ctx, BP_E_ARG, "bp_ipa_read: session has no H vector");
+  const u32 *sgx = s->gx, *sgy = s->gy, *shx = s->hx, *shy = s->hy;
+  const uint8_t *sgi = s->ginf, *shi = s->hinf;
+  if ((want_g || want_h) && n == 1 && n0 > 1) {
+    // fully folded: G = <cg, G0>, H = <ch, H0>, two sums in one MSM pass
+    MsmPart pg{s->gx, s->gy, s->ginf, s->cg, n0};
+    MsmPart ph{nullptr, nullptr, nullptr, nullptr, 0};
+    if (has_h) {
+      ph = MsmPart{s->hx, s->hy, s->hinf, s->ch, n0};
+      ph.group_lo = ph.group_hi = 1;
+    }
+    MsmPlan plan;
+    u32* d_win = nullptr;
+    CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2));
+    CHK(reserve_pinned(ctx, plan.win_bytes));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t* win = (const uint64_t*)ctx->pinned;
+    uint64_t g_xyz[12], h_xyz[12];
+    finish_windows(s->curve, win, plan.group_windows, plan.c, g_xyz);
+    finish_windows(s->curve, win + (size_t)plan.group_windows * 16, plan.group_windows, plan.c, h_xyz);
+    auto put = [](const uint64_t xyz[12], uint64_t* ox, uint64_t* oy, uint8_t* oinf) {
+      bool inf = !(xyz[8] | xyz[9] | xyz[10] | xyz[11]);
+      if (ox) memcpy(ox, xyz, 32);
+      if (oy) memcpy(oy, xyz + 4, 32);
+      if (oinf) *oinf = inf ? 1 : 0;
+    };
+    put(g_xyz, gx, gy, ginf);
+    if (has_h) put(h_xyz, hx, hy, hinf);
+    gx = gy = hx = hy = nullptr;
+    ginf = hinf = nullptr;
+  } else if ((want_g || want_h) && n < n0) {
+    // partially folded: replay the folds over the stored challenges
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) {
+      if (!*p && e == hipSuccess) e = hipMalloc(p, bytes);
+    };
+    const size_t cap = n0 / 2;
+    alloc((void**)&s->fgx, cap * 32); alloc((void**)&s->fgy, cap * 32); alloc((void**)&s->fginf, cap);
+    if (has_h) { alloc((void**)&s->fhx, cap * 32); alloc((void**)&s->fhy, cap * 32); alloc((void**)&s->fhinf, cap); }
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "bp_ipa_read: hipMalloc", e);
+    size_t len = n0;
+    for (size_t j = 0; j < s->x_canon.size(); j++) {
+      const size_t h = len / 2;
+      const FeArg xc = s->x_canon[j], xic = s->xinv_canon[j];
+      // G' = x^-1*G_lo + x*G_hi ; H' = x*H_lo + x^-1*H_hi (src/ipa/mod.rs:81-82)
+      FoldJob jg{sgx, sgy, sgi, sgx + h * 8, sgy + h * 8, sgi + h, s->fgx, s->fgy, s->fginf, xic, xc};
+      FoldJob jh{};
+      if (has_h) jh = FoldJob{shx, shy, shi, shx + h * 8, shy + h * 8, shi + h, s->fhx, s->fhy, s->fhinf, xc, xic};
+      e = launch_fold_generators2(s->curve, jg, jh, h, ctx->stream);
+      if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_generators", e);
+      sgx = s->fgx; sgy = s->fgy; sgi = s->fginf;
+      shx = s->fhx; shy = s->fhy; shi = s->fhinf;
+      len = h;
+    }
+  }
   struct { void* h; const void* d; size_t bytes; } cp[] = {
-      {gx, s->gx, n * 32}, {gy, s->gy, n * 32}, {ginf, s->ginf, n}, {hx, s->hx, n * 32},
-      {hy, s->hy, n * 32}, {hinf, s->hinf, n}, {a, s->a, n * 32}, {b, s->b, n * 32}};
+      {gx, sgx, n * 32}, {gy, sgy, n * 32}, {ginf, sgi, n}, {hx, shx, n * 32},
+      {hy, shy, n * 32}, {hinf, shi, n}, {a, s->a, n * 32}, {b, s->b, n * 32}};
   for (auto& c : cp) {
     if (!c.h) continue;
-    if (!c.d) return fail(ctx, BP_E_ARG, "bp_ipa_read: session has no H vector");
     HIPCHK(ctx, hipMemcpyAsync(c.h, c.d, c.bytes, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

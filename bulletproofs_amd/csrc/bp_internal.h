@@ -35,6 +35,14 @@ size_t s_vector_table_elems(int k);
 hipError_t launch_powers(int curve, FeArg x, size_t n, u32* table, u32* out, hipStream_t st);
 size_t powers_table_elems(size_t n);
 hipError_t launch_batch_inverse(int curve, int field, u32* v, size_t n, hipStream_t st);
+// IPA rounds over unfolded generators: per-generator coefficients cg, ch (n0 each; ch null for
+// the one-generator-vector variant) and the cross-term scalars eg, eh (n0 each) of the round
+// whose current length is 2*half.
+hipError_t launch_ipa_coef_update(int curve, u32* cg, u32* ch, size_t n0, size_t half, FeArg x, FeArg x_inv,
+                                  hipStream_t st);
+hipError_t launch_ipa_scalars(int curve, const u32* a, const u32* b, const u32* cg, const u32* ch, size_t n0,
+                              size_t half, u32* eg, u32* eh, hipStream_t st);
+hipError_t launch_fill_one(int curve, u32* v, size_t n, hipStream_t st);
 hipError_t launch_int_mad_peak(int iters, u32* sink, int blocks, hipStream_t st);
 
 // io: 1024*8 u32 of seed data; ids: 0 fe_mul pair, 1 add+sub pair, 2 xyzz_madd, 3 jac_dbl, 4 fe_mul (Vesta Fq)
@@ -71,11 +79,18 @@ struct MsmPart {
   const uint8_t* inf;  // may be null
   const u32* s;        // Montgomery-form scalars
   size_t n;
+  // Two-group plans only: which of the two sums a point contributes to.  sel_half == 0: the
+  // whole part goes to group_lo.  Otherwise index i goes to group_hi when
+  // (i mod 2*sel_half) >= sel_half and to group_lo when not (n must be a multiple of 2*sel_half).
+  size_t sel_half = 0;
+  u32 group_lo = 0, group_hi = 0;
 };
 
 struct MsmPlan {
   int c;          // window bits
-  int n_windows;  // W
+  int groups;     // independent sums computed in one pass (1 or 2)
+  int group_windows;  // windows per sum
+  int n_windows;  // over all groups; group g owns windows [g*group_windows, (g+1)*group_windows)
   int wshift;     // bit position of the window number inside a sorted value word
   u32 n_buckets;  // per window = 2^(c-1)
   size_t n_total; // points over both parts
@@ -90,7 +105,7 @@ struct MsmPlan {
 };
 
 int msm_choose_window(size_t n);
-hipError_t msm_make_plan(int curve, size_t n_total, int c_override, MsmPlan* plan);
+hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan);
 
 struct MsmWorkspace {
   u32* packed;        // points as x|y pairs, 16 u32 each

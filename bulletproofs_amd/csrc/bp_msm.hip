@@ -59,17 +59,20 @@ static int key_bits_for(u32 max_key) {
   return b;
 }
 
-hipError_t msm_make_plan(int curve, size_t n_total, int c_override, MsmPlan* plan) {
+hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan) {
   MsmPlan p{};
-  p.c = (c_override >= 2 && c_override <= 20) ? c_override : msm_choose_window(n_total);
+  if (groups < 1 || groups > 2) return hipErrorInvalidValue;
+  p.groups = groups;
+  p.c = (c_override >= 2 && c_override <= 20) ? c_override : msm_choose_window(n_total / groups);
   // k_digits maps a scalar k > r/2 to r - k (and negates the point), so digits
   // come from a value below 2^255 (secp256k1) or 2^254 (Vesta); one more bit
   // absorbs the carry of the signed recoding.
   const int value_bits = curve == BP_VESTA ? 254 : 255;
-  p.n_windows = (value_bits + 1 + p.c - 1) / p.c;
+  p.group_windows = (value_bits + 1 + p.c - 1) / p.c;
+  p.n_windows = p.group_windows * groups;
   p.n_buckets = 1u << (p.c - 1);
   p.n_total = n_total;
-  p.entries = (size_t)p.n_windows * n_total;
+  p.entries = (size_t)p.group_windows * n_total;
   if (p.entries >= (1ull << 31)) return hipErrorInvalidValue;
   p.seg_len = p.n_buckets < 16 ? (int)p.n_buckets : 16;
   p.n_segs = p.n_buckets / p.seg_len;
@@ -115,6 +118,12 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, MsmPlan* pla
 }
 
 // ---- 1. digits --------------------------------------------------------------
+// Group selection of the two parts (see MsmPart): half == 0 puts the whole part in group lo.
+struct DigitGroups {
+  u32 half0, half1;
+  u32 lo0, hi0, lo1, hi1;
+};
+
 template <class C>
 __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, const uint8_t* __restrict__ inf0,
                                                 size_t n0, const u32* __restrict__ s1,
@@ -123,11 +132,32 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
                                                 u32* __restrict__ keys, u32* __restrict__ vals,
                                                 const u32* __restrict__ x0,
                                                 const u32* __restrict__ y0, const u32* __restrict__ x1,
-                                                const u32* __restrict__ y1, u32* __restrict__ packed) {
+                                                const u32* __restrict__ y1, u32* __restrict__ packed,
+                                                DigitGroups sel) {
   using Fr = typename C::Fr;
   size_t n = n0 + n1;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  // Output group of this point and its position inside a window's slice of the entry
+  // table.  Positions put group 0 before group 1, so that after the stable sort on the
+  // bucket number the entries of one (bucket, window, group) are still contiguous.
+  u32 grp;
+  size_t pos;
+  {
+    const bool second = i >= n0;
+    const u32 half_sel = second ? sel.half1 : sel.half0;
+    if (half_sel == 0) {
+      grp = second ? sel.lo1 : sel.lo0;
+      pos = i;
+    } else {
+      size_t li = second ? i - n0 : i;
+      size_t q = li / (2 * (size_t)half_sel), r = li % (2 * (size_t)half_sel);
+      bool up = r >= half_sel;
+      grp = up ? (second ? sel.hi1 : sel.hi0) : (second ? sel.lo1 : sel.lo0);
+      pos = (size_t)grp * (n / 2) + (second ? n0 / 2 : 0) + q * half_sel + (up ? r - half_sel : r);
+    }
+  }
+  const u32 wbase = grp * (u32)n_windows;
   // x and y of a point side by side (64 contiguous bytes): the accumulation kernel
   // gathers points in bucket order, and one 64-byte piece costs half the memory
   // transactions of two 32-byte pieces from separate planes
@@ -182,15 +212,15 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
       carry = 1;
       u32 mag = (1u << c) - v;  // |v - 2^c|
       key = mag ? mag - 1 : invalid;  // v == 2^c: digit 0, carry 1
-      val = ((u32)i | ((u32)w << wshift) | 0x80000000u) ^ flip;
+      val = ((u32)i | ((wbase + (u32)w) << wshift) | 0x80000000u) ^ flip;
     } else {
       carry = 0;
       key = v ? v - 1 : invalid;
-      val = ((u32)i | ((u32)w << wshift)) ^ flip;
+      val = ((u32)i | ((wbase + (u32)w) << wshift)) ^ flip;
     }
     if (is_inf) key = invalid;
-    keys[(size_t)w * n + i] = key;
-    vals[(size_t)w * n + i] = val;
+    keys[(size_t)w * n + pos] = key;
+    vals[(size_t)w * n + pos] = val;
   }
 }
 
@@ -472,10 +502,19 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPla
     // all windows = identity (zz = 0)
     return hipMemsetAsync(ws.windows, 0, plan.win_bytes, st);
   }
+  DigitGroups sel{(u32)p0.sel_half, (u32)p1.sel_half, p0.group_lo, p0.group_hi, p1.group_lo, p1.group_hi};
+  if (plan.groups == 1) sel = DigitGroups{0, 0, 0, 0, 0, 0};
+  // split parts must tile evenly, and split and whole parts cannot be mixed
+  if (plan.groups == 2) {
+    if ((p0.sel_half != 0) != (p1.sel_half != 0) && p0.n && p1.n) return hipErrorInvalidValue;
+    if (p0.sel_half && p0.n % (2 * p0.sel_half)) return hipErrorInvalidValue;
+    if (p1.sel_half && p1.n % (2 * p1.sel_half)) return hipErrorInvalidValue;
+    if (!p0.sel_half && !p1.sel_half && p0.n && p1.n && p0.group_lo > p1.group_lo) return hipErrorInvalidValue;
+  }
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_digits<C>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                            st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, plan.c,
-                                           plan.n_windows, plan.n_buckets, plan.wshift, ws.keys_a, ws.vals_a, p0.x, p0.y, p1.x, p1.y,
-                                           ws.packed));
+                                           plan.group_windows, plan.n_buckets, plan.wshift, ws.keys_a, ws.vals_a, p0.x, p0.y, p1.x, p1.y,
+                                           ws.packed, sel));
   if ((e = hipGetLastError()) != hipSuccess) return e;
   size_t tmp = plan.sort_tmp_bytes;
   e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(

@@ -330,6 +330,71 @@ hipError_t launch_batch_inverse(int curve, int field, u32* v, size_t n, hipStrea
   return hipGetLastError();
 }
 
+// ---- IPA rounds over unfolded generators ----------------------------------------
+// After j rounds the folded generator G_i (i < n_j = n0 / 2^j) of src/ipa/mod.rs:80-83 is
+//   G_i = sum_{k = i mod n_j} cg[k] * G0_k,   cg[k] = prod_t (k in the upper half at round t ? x_t : x_t^-1)
+// (H likewise with the roles of x_t and x_t^-1 swapped).  The prover only ever needs the
+// cross terms L, R, so instead of folding the generators (a ~450-step dependent chain of
+// curve operations per output and round) it keeps G0, H0 and multiplies the coefficients
+// into the MSM scalars.
+template <class F>
+__global__ __launch_bounds__(256) void k_ipa_coef_update(u32* __restrict__ cg, u32* __restrict__ ch, size_t n0,
+                                                         size_t half, FeArg xa, FeArg xia) {
+  // half = n_j / 2 of the round being folded: index k goes to the upper half iff (k mod n_j) >= half
+  const Fe x = arg_to_fe(xa), xi = arg_to_fe(xia);
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n0) return;
+  bool upper = (k & (2 * half - 1)) >= half;
+  fe_store(cg + k * 8, fe_mul<F>(fe_load(cg + k * 8), upper ? x : xi));
+  if (ch) fe_store(ch + k * 8, fe_mul<F>(fe_load(ch + k * 8), upper ? xi : x));
+}
+
+// Scalars of the cross-term MSMs over the unfolded generators for the current round: generator k
+// (position i = k mod 2*half of the folded vector) is paired with the element of the other half,
+//   eg[k] = cg[k] * a[i -+ half],  eh[k] = ch[k] * b[i -+ half].
+// Upper-half G and lower-half H entries belong to L (src/ipa/mod.rs:44-54: G_hi with a_lo, H_lo
+// with b_hi), the others to R (:60-70); the poly-commit variant has no H (ch == null;
+// src/poly_commit/mod.rs:78,83).
+template <class F>
+__global__ __launch_bounds__(256) void k_ipa_scalars(const u32* __restrict__ a, const u32* __restrict__ b,
+                                                     const u32* __restrict__ cg, const u32* __restrict__ ch,
+                                                     size_t n0, size_t half, u32* __restrict__ eg,
+                                                     u32* __restrict__ eh) {
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n0) return;
+  size_t i = k & (2 * half - 1);
+  size_t other = i >= half ? i - half : i + half;
+  fe_store(eg + k * 8, fe_mul<F>(fe_load(cg + k * 8), fe_load(a + other * 8)));
+  if (ch) fe_store(eh + k * 8, fe_mul<F>(fe_load(ch + k * 8), fe_load(b + other * 8)));
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_fill_one(u32* __restrict__ v, size_t n) {
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) fe_store(v + k * 8, fe_one<F>());
+}
+
+hipError_t launch_ipa_coef_update(int curve, u32* cg, u32* ch, size_t n0, size_t half, FeArg x, FeArg x_inv,
+                                  hipStream_t st) {
+  unsigned blocks = (unsigned)((n0 + 255) / 256);
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipa_coef_update<F>, dim3(blocks), dim3(256), 0, st, cg, ch, n0, half, x, x_inv));
+  return hipGetLastError();
+}
+
+hipError_t launch_ipa_scalars(int curve, const u32* a, const u32* b, const u32* cg, const u32* ch, size_t n0,
+                              size_t half, u32* eg, u32* eh, hipStream_t st) {
+  unsigned blocks = (unsigned)((n0 + 255) / 256);
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipa_scalars<F>, dim3(blocks), dim3(256), 0, st, a, b, cg, ch, n0, half, eg, eh));
+  return hipGetLastError();
+}
+
+hipError_t launch_fill_one(int curve, u32* v, size_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_fill_one<F>, dim3(blocks), dim3(256), 0, st, v, n));
+  return hipGetLastError();
+}
+
 // ---- integer multiply-accumulate peak probe -----------------------------------
 // 32 independent 64-bit accumulators per lane, 8 v_mad_u64_u32 each per loop
 // iteration (256 per iteration), nothing else in the loop but its counter: the
