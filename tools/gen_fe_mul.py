@@ -9,6 +9,12 @@ carry-out into ovf.  All products of a column that share an operand kind sit in 
 asm statement (the compiler pads every asm statement with an s_nop, so few large
 statements beat many small ones).  Modulus limbs equal to 0 are skipped, limbs equal
 to 0xffffffff / 1 use inline constants, the rest are SGPR operands.
+
+A run of top limbs p_s..p_7 that are all 0xffffffff (secp256k1: s = 2 for the base
+field, 5 for the scalar field) is not multiplied out: m * sum_{j=s..7} p_j 2^(32j) =
+m * (2^256 - 2^(32s)), so m_i is subtracted from column i+s and added to column i+8.
+The accumulator is then a signed (two's complement) 96-bit value and the shift to the
+next column sign-extends it.
 """
 import os
 
@@ -60,9 +66,20 @@ def const_ref(asm, value):
     return asm.operand("s", "0x%08xu" % value)
 
 
+def ones_run_start(pl):
+    """first limb of the run of 0xffffffff limbs that ends at limb 7 (8 if the run is
+    shorter than 3 limbs: then multiplying out is no more expensive)"""
+    s = 8
+    while s > 0 and pl[s - 1] == 0xFFFFFFFF:
+        s -= 1
+    return s if 8 - s >= 3 and s >= 1 else 8
+
+
 def gen_field(name, p):
     pl = limbs(p)
     inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
+    run = ones_run_start(pl)
+    signed = run < 8
     out = []
     out.append("// %s: p = 0x%064x" % (name, p))
     out.append("__device__ __forceinline__ Fe fe_mul_dev_%s(const Fe& a, const Fe& b) {" % name)
@@ -81,9 +98,18 @@ def gen_field(name, p):
         mp = Asm()
         for i in range(8):
             j = k - i
-            if 0 <= j <= 7 and not (k < 8 and i == k) and pl[j] != 0:
+            if 0 <= j <= 7 and not (k < 8 and i == k) and pl[j] != 0 and j < run:
                 mp.mac(mp.operand("v", "m%d" % i), const_ref(mp, pl[j]))
+        if signed and 0 <= k - 8 <= 7:
+            mp.mac(mp.operand("v", "m%d" % (k - 8)), "1")
         mp.emit(out)
+        if signed and 0 <= k - run <= 7:
+            out.append("  {  // acc:ovf -= m%d" % (k - run))
+            out.append("    uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);")
+            out.append('    asm("v_sub_co_u32 %0, vcc, %0, %3\\n\\tv_subbrev_co_u32 %1, vcc, 0, %1, vcc\\n\\tv_subbrev_co_u32 %2, vcc, 0, %2, vcc"')
+            out.append('        : "+v"(lo), "+v"(hi), "+v"(ovf) : "v"(m%d) : "vcc");' % (k - run))
+            out.append("    acc = lo | ((uint64_t)hi << 32);")
+            out.append("  }")
         if k < 8:
             out.append("  m%d = (uint32_t)acc * 0x%08xu;" % (k, inv))
             last = Asm()
@@ -92,7 +118,9 @@ def gen_field(name, p):
         else:
             out.append("  r.v[%d] = (uint32_t)acc;" % (k - 8))
         out.append("  acc = (acc >> 32) | ((uint64_t)ovf << 32);")
-        out.append("  ovf = 0;")
+        out.append("  ovf = (uint32_t)((int32_t)ovf >> 31);" if signed and k >= run else "  ovf = 0;")
+    if signed:
+        out.append("  acc += m7;  // column 15")
     out.append("  r.v[7] = (uint32_t)acc;")
     out.append("  return fe_reduce_once<%s>(r, (uint32_t)(acc >> 32));" % name)
     out.append("}")
