@@ -28,7 +28,7 @@ namespace bp {
 // the kernel is bound by the latency of its ~450-step dependent chain, not by
 // throughput, until h reaches several 10^5.
 template <class C>
-__global__ __launch_bounds__(128) void k_fold_generators(FoldJob j0, FoldJob j1, size_t h) {
+__global__ __launch_bounds__(256) void k_fold_generators(FoldJob j0, FoldJob j1, size_t h) {
   using F = typename C::Fq;
   // a block belongs to one job, so the bit schedule stays uniform within a wave
   const unsigned blocks_per_job = (unsigned)((h + blockDim.x - 1) / blockDim.x);
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(128) void k_fold_generators(FoldJob j0, FoldJob j1,
 
 hipError_t launch_fold_generators2(int curve, const FoldJob& j0, const FoldJob& j1, size_t h, hipStream_t st) {
   if (h == 0) return hipSuccess;
-  unsigned blocks = (unsigned)((h + 127) / 128) * (j1.lx ? 2u : 1u);
-  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_fold_generators<C>, dim3(blocks), dim3(128), 0, st, j0, j1, h));
+  unsigned blocks = (unsigned)((h + 255) / 256) * (j1.lx ? 2u : 1u);
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_fold_generators<C>, dim3(blocks), dim3(256), 0, st, j0, j1, h));
   return hipGetLastError();
 }
 
@@ -88,7 +88,7 @@ hipError_t launch_fold_generators(int curve, const u32* lx, const u32* ly, const
 // out[i] = s[i] * P[i]  (src/range/aggregate.rs:148-153).  Per-point scalars, so
 // the add branch diverges; the doublings stay uniform.
 template <class C>
-__global__ __launch_bounds__(128) void k_scale_points(const u32* __restrict__ px,
+__global__ __launch_bounds__(256) void k_scale_points(const u32* __restrict__ px,
                                                       const u32* __restrict__ py,
                                                       const uint8_t* __restrict__ pinf,
                                                       const u32* __restrict__ s, size_t n,
@@ -122,15 +122,15 @@ hipError_t launch_scale_points(int curve, const u32* px, const u32* py, const ui
                                const u32* s, size_t n, u32* ox, u32* oy, uint8_t* oinf,
                                hipStream_t st) {
   if (n == 0) return hipSuccess;
-  unsigned blocks = (unsigned)((n + 127) / 128);
-  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_scale_points<C>, dim3(blocks), dim3(128), 0, st, px, py,
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_scale_points<C>, dim3(blocks), dim3(256), 0, st, px, py,
                                            pinf, s, n, ox, oy, oinf));
   return hipGetLastError();
 }
 
 // Jacobian (X,Y,Z interleaved, 24 u32 per point) -> affine planes
 template <class C>
-__global__ __launch_bounds__(128) void k_normalize_jac(const u32* __restrict__ xyz, size_t n,
+__global__ __launch_bounds__(256) void k_normalize_jac(const u32* __restrict__ xyz, size_t n,
                                                        u32* __restrict__ ox, u32* __restrict__ oy,
                                                        uint8_t* __restrict__ oinf) {
   using F = typename C::Fq;
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(128) void k_normalize_jac(const u32* __restrict__ x
 hipError_t launch_normalize_jac(int curve, const u32* xyz, size_t n, u32* ox, u32* oy, uint8_t* oinf,
                                 hipStream_t st) {
   if (n == 0) return hipSuccess;
-  unsigned blocks = (unsigned)((n + 127) / 128);
-  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_normalize_jac<C>, dim3(blocks), dim3(128), 0, st, xyz, n,
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_normalize_jac<C>, dim3(blocks), dim3(256), 0, st, xyz, n,
                                            ox, oy, oinf));
   return hipGetLastError();
 }

@@ -10,6 +10,7 @@
 // strictly sequential chain of ~256 doublings, slower on a GPU lane than on a CPU
 // core).  Stands in for ark-ec 0.5.0 VariableBaseMSM::msm_unchecked as called at
 // src/msm.rs:84-87 and the direct call sites listed in include/bp_gpu.h.
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -45,12 +46,17 @@ static inline int ilog2_floor(size_t n) {
   return l;
 }
 
+// Window width by problem size, from measurements with uniform scalars on MI355X.  Widths
+// that divide 256 (4, 8, 16) leave no short top window: a top window of t bits puts all
+// points into 2^(t-1) buckets, which then need a deep tree of partial sums.
 int msm_choose_window(size_t n) {
-  if (n <= 1) return 4;
-  int c = ilog2_floor(n) - 3;
-  if (c < 4) c = 4;
-  if (c > 16) c = 16;
-  return c;
+  int l = ilog2_floor(n ? n : 1);
+  if (l >= 17) return 16;
+  if (l >= 14) return 13;
+  if (l == 13) return 11;
+  if (l == 12) return 10;
+  if (l >= 9) return 8;
+  return 4;
 }
 
 static int key_bits_for(u32 max_key) {
@@ -74,7 +80,13 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   p.n_total = n_total;
   p.entries = (size_t)p.group_windows * n_total;
   if (p.entries >= (1ull << 31)) return hipErrorInvalidValue;
-  p.seg_len = p.n_buckets < 16 ? (int)p.n_buckets : 16;
+  // Buckets per reduction lane: the reduction is a dependent chain of 2*seg_len additions
+  // plus a multiplication by the segment offset, so short segments win as long as the
+  // lanes still fit the machine about once (256 CUs * 4 SIMDs * 64 lanes).
+  p.seg_len = 16;
+  while (p.seg_len > 4 && (size_t)p.n_windows * p.n_buckets / (p.seg_len / 2) <= 65536) p.seg_len /= 2;
+  if (const char* ev = getenv("BP_MSM_SEG_LEN")) p.seg_len = atoi(ev);
+  if ((u32)p.seg_len > p.n_buckets) p.seg_len = (int)p.n_buckets;
   p.n_segs = p.n_buckets / p.seg_len;
   size_t nbt = (size_t)p.n_windows * p.n_buckets;
   p.keys_bytes = ((p.entries * sizeof(u32)) + 255) & ~(size_t)255;
@@ -100,6 +112,9 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   // there are still tens of thousands of lanes
   size_t t = p.entries / 65536;
   p.chunk = (u32)(t < 4 ? 4 : (t > 32 ? 32 : t));
+  // very large inputs: about 2^21 chunks are plenty of lanes, and longer chunks keep the
+  // number of partial sums per bucket small
+  if ((p.entries >> 21) > p.chunk) p.chunk = (u32)((p.entries >> 21) > 4096 ? 4096 : (p.entries >> 21));
   p.nc_cap = p.entries / p.chunk + nbt + 1;
   p.nch_bytes = ((nbt + 2) * sizeof(u32) + 255) & ~(size_t)255;
   p.chunk_sum_bytes = p.nc_cap * 4 * 32;
@@ -312,7 +327,8 @@ __global__ __launch_bounds__(256) void k_chunk_desc(const u32* __restrict__ star
   u32 len = e - s > chunk ? chunk : e - s;
   desc_b[t] = (u32)lo;
   desc_s[t] = s;
-  ckey[t] = chunk - len;
+  // 0 = full chunk ... kChunkKeyInvalid - 1 = shortest
+  ckey[t] = chunk < kChunkKeyInvalid ? chunk - len : (u32)((size_t)(chunk - len) * (kChunkKeyInvalid - 1) / chunk);
 }
 
 template <class C>
@@ -322,6 +338,7 @@ __global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ pack
                                                     const u32* __restrict__ cval,
                                                     const u32* __restrict__ desc_b,
                                                     const u32* __restrict__ desc_s,
+                                                    const u32* __restrict__ bucket_end,
                                                     const u32* __restrict__ nch, size_t nbt, u32 chunk,
                                                     size_t nc_cap, u32 idx_mask, u32* __restrict__ buckets,
                                                     u32* __restrict__ chunk_sums) {
@@ -332,7 +349,11 @@ __global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ pack
   if (key == kChunkKeyInvalid) return;
   u32 t = cval[j];
   u32 b = desc_b[t];
-  u32 s = desc_s[t], e = s + (chunk - key);
+  u32 s = desc_s[t], e = s + chunk;
+  {
+    u32 be = bucket_end[b];
+    e = e < be ? e : be;
+  }
   Xyzz acc = xyzz_identity<F>();
   for (u32 p = s; p < e; p++) {
     u32 v = vals[p];
@@ -416,7 +437,7 @@ __global__ __launch_bounds__(256) void k_bucket_heavy(const u32* __restrict__ nc
 // buckets: T = sum (j-j0+1)*B_j by a running sum, S = sum B_j, and emits
 // T + j0*S (j0*S by double-and-add on a < 2^19 multiplier).
 template <class C>
-__global__ __launch_bounds__(128) void k_reduce_segments(const u32* __restrict__ buckets, size_t nbt,
+__global__ __launch_bounds__(256) void k_reduce_segments(const u32* __restrict__ buckets, size_t nbt,
                                                          u32 n_buckets, int seg_len, u32 n_segs,
                                                          int n_windows, u32* __restrict__ segs) {
   using F = typename C::Fq;
@@ -432,10 +453,24 @@ __global__ __launch_bounds__(128) void k_reduce_segments(const u32* __restrict__
     xyzz_add<F>(acc, run);
   }
   if (j0 != 0 && !xyzz_is_identity(run)) {
-    Xyzz m = xyzz_identity<F>();
-    for (int b = 31 - __clz(j0); b >= 0; b--) {
-      m = xyzz_dbl<F>(m);
-      if ((j0 >> b) & 1) xyzz_add<F>(m, run);
+    // j0 * run, right to left over the non-adjacent form of j0 (digits 0, +1, -1; at most
+    // every other digit is non-zero, which matters because a wave pays for an addition
+    // whenever any of its lanes has one)
+    Xyzz m = xyzz_identity<F>(), pw = run;
+    u32 k = j0;
+    while (k) {
+      if (k & 1) {
+        Xyzz term = pw;
+        if (k & 2) {
+          term.y = fe_neg<F>(term.y);
+          k += 1;
+        } else {
+          k -= 1;
+        }
+        xyzz_add<F>(m, term);
+      }
+      k >>= 1;
+      if (k) pw = xyzz_dbl<F>(pw);
     }
     xyzz_add<F>(acc, m);
   }
@@ -543,7 +578,7 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPla
   if (ev_acc0 && (e = hipEventRecord(ev_acc0, st)) != hipSuccess) return e;
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_chunk_sums<C>, dim3((unsigned)((plan.nc_cap + 127) / 128)), dim3(128),
                                            0, st, ws.packed, ws.vals_b, ws.ckey_b, ws.cval_b,
-                                           ws.desc_b, ws.desc_s, ws.nch, nbt, plan.chunk, plan.nc_cap, (1u << plan.wshift) - 1u, ws.buckets,
+                                           ws.desc_b, ws.desc_s, ws.bucket_end, ws.nch, nbt, plan.chunk, plan.nc_cap, (1u << plan.wshift) - 1u, ws.buckets,
                                            ws.chunk_sums));
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;
@@ -556,7 +591,10 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPla
   if ((e = hipGetLastError()) != hipSuccess) return e;
   size_t nseg_threads = (size_t)plan.n_windows * plan.n_segs;
   DISPATCH_CURVE(curve, {
-    hipLaunchKernelGGL(k_reduce_segments<C>, dim3((unsigned)((nseg_threads + 127) / 128)), dim3(128), 0, st,
+    // 256-lane blocks: one wave on each SIMD of a CU.  The kernel is a long dependent chain
+    // per lane, and with smaller blocks the dispatcher stacks waves of different blocks on
+    // one SIMD while others idle.
+    hipLaunchKernelGGL(k_reduce_segments<C>, dim3((unsigned)((nseg_threads + 255) / 256)), dim3(256), 0, st,
                        ws.buckets, nbt, plan.n_buckets, plan.seg_len, plan.n_segs, plan.n_windows,
                        ws.segs);
     // window value = sum of its segment values, in one or two tree stages

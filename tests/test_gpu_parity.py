@@ -227,6 +227,29 @@ def test_msm_full_size_properties(ctx, coracle):
     assert r3 == o.add(r1, r2, c)
 
 
+def test_msm_beyond_baseline_size(ctx, coracle):
+    """2^23 points (8 copies of 2^20): sum_j <K_j, P> == <sum_j K_j, P>.  At this size the
+    accumulation chunks are longer than at 2^20, whose result the closed form pins."""
+    import torch
+
+    c = o.SECP256K1
+    n, reps = 1 << 20, 8
+    px, py = seeded_points(coracle, c, n, 5550123, 7)
+    rng = np.random.default_rng(23)
+    K = rng.integers(0, 1 << 64, (n * reps, 4), dtype=np.uint64)
+    K[:, 3] &= np.uint64((1 << 62) - 1)  # any value below the modulus is a valid element
+    dx, dy, dk = _dev(px).repeat(reps, 1), _dev(py).repeat(reps, 1), _dev(K)
+    big = ctx.msm_dev(c.id, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n * reps)
+    ksum = K[:n]
+    for j in range(1, reps):
+        ksum = ctx.vector_add(c.id, ksum, K[j * n:(j + 1) * n])
+    ds = _dev(ksum)
+    small = ctx.msm_dev(c.id, dx.data_ptr(), dy.data_ptr(), None, ds.data_ptr(), n)
+    assert np.array_equal(big, small)
+    del dx, dy, dk
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("c", CURVES, ids=ids)
 def test_msm_resident_and_two_part(ctx, coracle, c):
     n = 3000
