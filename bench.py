@@ -32,6 +32,12 @@ LOG2_N = 20
 SEED = 0xB0117E7 + 2  # config index 2 of BASELINE.json ("Standalone MSM 2^16..2^20")
 MADD_MULS = 10        # XYZZ mixed addition: 8M + 2S
 MAC_PER_MUL = 136     # 8-limb Montgomery multiply: 2*8*8 + 8 32x32 multiply-accumulates
+# Memory-side bytes of one k_chunk_sums launch at the default size, from separate
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script (averages over the
+# launches; profiles/r01_bench_msm20_v2_pmc_summary.csv).  The counters read KiB; a
+# scattered read of 64-byte records with a known byte count (tools/calib_gather.py,
+# profiles/r01_gather64_calibration.csv) reads back exactly, so no factor is applied.
+PMC_TRAFFIC_2_20 = {"fetch_bytes": 1732210.4 * 1024, "write_bytes": 95412.3 * 1024}
 
 
 def make_inputs(n, rank):
@@ -207,7 +213,9 @@ def main():
                 "frac": achieved / peak,
                 "avg_launch_ms": acc_avg_s * 1e3,
                 "algorithmic_mac_per_point": nw * MADD_MULS * MAC_PER_MUL,
-                "traffic": None,
+                "traffic": (PMC_TRAFFIC_2_20["fetch_bytes"] + PMC_TRAFFIC_2_20["write_bytes"]) if args.log2n == LOG2_N else None,
+                "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc runs; see profiles/)",
+                "algorithmic_bytes": float(n) * nw * (64 + 4),
             },
         }
         if not args.no_cpu_baseline and world == 1:

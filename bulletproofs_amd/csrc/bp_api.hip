@@ -949,6 +949,23 @@ int bp_microbench(bp_ctx* ctx, int id, int blocks, int iters, float* ms) {
   if (!ctx || !ms || blocks < 1 || iters < 1) return fail(ctx, BP_E_ARG, "bp_microbench: bad argument");
   Guard g(ctx);
   void* io;
+  if (id == 5) {
+    if (iters < 10 || iters > 26) return fail(ctx, BP_E_ARG, "bp_microbench: id 5 takes 10 <= iters <= 26");
+    const size_t records = (size_t)1 << iters;
+    void* table;
+    CHK(reserve(ctx, S_PACKED, records * 64, &table));
+    CHK(reserve(ctx, S_SMALL, 256, &io));
+    HIPCHK(ctx, hipMemsetAsync(table, 0x5a, records * 64, ctx->stream));
+    hipError_t ge = launch_gather_bench((const u32*)table, records, (u32*)io, ctx->stream);
+    if (ge != hipSuccess) return fail(ctx, BP_E_HIP, "bp_microbench: gather", ge);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    ge = launch_gather_bench((const u32*)table, records, (u32*)io, ctx->stream);
+    if (ge != hipSuccess) return fail(ctx, BP_E_HIP, "bp_microbench: gather", ge);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev[4], ctx->ev[5]));
+    return BP_OK;
+  }
   CHK(reserve(ctx, S_TABLE, 1024 * 32, &io));
   std::vector<uint32_t> seed(1024 * 8);
   uint64_t s = 0x9E3779B97F4A7C15ull;

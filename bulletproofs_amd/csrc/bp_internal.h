@@ -47,6 +47,8 @@ hipError_t launch_int_mad_peak(int iters, u32* sink, int blocks, hipStream_t st)
 
 // io: 1024*8 u32 of seed data; ids: 0 fe_mul pair, 1 add+sub pair, 2 xyzz_madd, 3 jac_dbl, 4 fe_mul (Vesta Fq)
 hipError_t launch_microbench(int id, int blocks, int iters, u32* io, hipStream_t st);
+// records: power of two; table: records * 16 u32
+hipError_t launch_gather_bench(const u32* table, size_t records, u32* sink, hipStream_t st);
 
 // ---- curve-vector kernels (bp_curvevec.hip) ----
 // scalars are canonical (non-Montgomery) little-endian 256-bit integers here

@@ -50,6 +50,26 @@ __global__ __launch_bounds__(128) void k_mb_jdbl(int iters, u32* __restrict__ io
   if (a.x.v[0] == 0x12345 && a.y.v[3] == 0x54321) fe_store(io, a.x);
 }
 
+// Reads every 64-byte record of a table exactly once, in a scattered order (lane t reads
+// record t*mult mod records, mult odd), with the four 16-byte loads per lane that the MSM
+// accumulation kernel uses for its point gathers: a known byte count in that access
+// pattern, against which the memory-side counters can be calibrated.
+__global__ __launch_bounds__(128) void k_mb_gather64(const u32* __restrict__ table, size_t records,
+                                                     u32* __restrict__ sink) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= records) return;
+  size_t idx = (t * 0x9E3779B1ull) & (records - 1);
+  const uint4* q = reinterpret_cast<const uint4*>(table + idx * 16);
+  uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  u32 x = a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+  if (x == 0x1234567u) sink[0] = x;
+}
+
+hipError_t launch_gather_bench(const u32* table, size_t records, u32* sink, hipStream_t st) {
+  hipLaunchKernelGGL(k_mb_gather64, dim3((unsigned)((records + 127) / 128)), dim3(128), 0, st, table, records, sink);
+  return hipGetLastError();
+}
+
 hipError_t launch_microbench(int id, int blocks, int iters, u32* io, hipStream_t st) {
   using F = Secp256k1Fq;
   switch (id) {

@@ -205,7 +205,10 @@ int bp_bench_int_mad_peak(bp_ctx* ctx, int iters, double* mac_per_s);
 /* Times one launch (after a warm-up launch) of an arithmetic micro-benchmark:
  * id 0 = 2*iters dependent Fq multiplies per lane (secp256k1), 1 = iters add+sub
  * pairs, 2 = iters XYZZ mixed additions, 3 = iters Jacobian doublings, 4 = as 0 on
- * Vesta's Fq.  256 (ids 0,1,4) or 128 lanes per block. */
+ * Vesta's Fq.  256 (ids 0,1,4) or 128 lanes per block.
+ * id 5 = scattered read of every 64-byte record of a 2^iters-record table exactly once
+ * (the MSM point-gather pattern with a known byte count, 64 * 2^iters, for calibrating
+ * memory counters); `blocks` is ignored, 10 <= iters <= 26. */
 int bp_microbench(bp_ctx* ctx, int id, int blocks, int iters, float* ms);
 /* Duration in ms of the most recent launch of the named kernel group on this
  * context, measured with HIP events on the context's stream.
