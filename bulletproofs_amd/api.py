@@ -229,6 +229,9 @@ class Context:
     def ipa_begin(self, curve, variant, gs, hs, a, b):
         return IpaSession(self, curve, variant, gs, hs, a, b)
 
+    def ipa_begin_resident(self, bases, variant, g_offset, h_offset, a, b):
+        return IpaSession(self, bases.curve, variant, None, None, a, b, resident=bases, g_offset=g_offset, h_offset=h_offset)
+
 
 class Bases:
     """Device-resident base points (bp_bases): the CRS uploaded once."""
@@ -267,10 +270,16 @@ class IpaSession:
     """Device-resident G, H, a, b across the rounds of ipa::prove
     (src/ipa/mod.rs:33-95) or poly_commit::prove (src/poly_commit/mod.rs:69-105)."""
 
-    def __init__(self, ctx: Context, curve, variant, gs, hs, a, b):
-        gx, gy, gi = _pts(gs)
+    def __init__(self, ctx: Context, curve, variant, gs, hs, a, b, resident=None, g_offset=0, h_offset=0):
         a, b = _f(a), _f(b)
         n = a.shape[0]
+        if resident is not None:
+            # generators come from a registered base set (bp_ipa_begin_resident), not copied
+            h = C.c_void_p()
+            ctx._chk(lib.bp_ipa_begin_resident(ctx.h, resident.h, variant, g_offset, h_offset, _p(a), _p(b), n, C.byref(h)))
+            self.ctx, self.h, self.has_h, self._bases = ctx, h, variant == 0, resident
+            return
+        gx, gy, gi = _pts(gs)
         if hs is not None:
             hx, hy, hi = _pts(hs)
         else:
@@ -291,6 +300,16 @@ class IpaSession:
         cr = np.zeros(4, dtype=np.uint64)
         self.ctx._chk(lib.bp_ipa_round_lr(self.h, _p(L), _p(R), _p(cl), _p(cr)))
         return L, R, cl, cr
+
+    def scale_h(self, scale):
+        """session continues as if H_i were scale_i * H_i (hs' of src/range/aggregate.rs:148-153)"""
+        sc = _f(scale)
+        self.ctx._chk(lib.bp_ipa_scale_h(self.h, _p(sc)))
+
+    def set_u(self, u_xy):
+        """u as 8 u64 (x|y): round_lr then returns L, R including c_l*u, c_r*u"""
+        u = None if u_xy is None else np.ascontiguousarray(u_xy, dtype=np.uint64).reshape(8)
+        self.ctx._chk(lib.bp_ipa_set_u(self.h, _p(u)))
 
     def round_fold(self, x, x_inv):
         x, xi = _f(x), _f(x_inv)

@@ -40,6 +40,8 @@ struct bp_ctx {
   hipEvent_t ev[6] = {};
   int c_override = 0;
   float last_ms[3] = {0, 0, 0};
+  void* ipa_cache = nullptr;  // device block of the last freed IPA session, reused by the next
+  size_t ipa_cache_bytes = 0;
 };
 
 struct bp_bases {
@@ -61,11 +63,17 @@ struct bp_ipa {
   int variant = 0;
   size_t n = 0;   // current length of a, b
   size_t n0 = 0;  // length at bp_ipa_begin
-  u32 *gx = nullptr, *gy = nullptr, *hx = nullptr, *hy = nullptr;  // n0 points each, as given
-  uint8_t *ginf = nullptr, *hinf = nullptr;
+  // n0 points each, as given: inside `block`, or inside a registered base set
+  const u32 *gx = nullptr, *gy = nullptr, *hx = nullptr, *hy = nullptr;
+  const uint8_t *ginf = nullptr, *hinf = nullptr;
+  void* block = nullptr;             // one allocation behind every pointer below up to `dots`
+  size_t block_bytes = 0;
   u32 *a = nullptr, *b = nullptr;    // folded in place
   u32 *cg = nullptr, *ch = nullptr;  // n0 coefficients each
   u32 *eg = nullptr, *eh = nullptr;  // n0 cross-term scalars each
+  u32* u_xy = nullptr;               // the point u (x|y) when has_u
+  bool has_u = false;
+  u32* dots = nullptr;               // partial sums and results of the two inner products
   // folded generators, materialised on demand (n0/2 points each)
   u32 *fgx = nullptr, *fgy = nullptr, *fhx = nullptr, *fhy = nullptr;
   uint8_t *fginf = nullptr, *fhinf = nullptr;
@@ -174,8 +182,8 @@ void finish_windows(int curve, const uint64_t* win, int n_windows, int c, uint64
 
 // device phase of an MSM: leaves plan->n_windows XYZZ window sums in S_WINDOWS
 int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, MsmPlan* plan,
-               u32** d_windows, int groups = 1) {
-  size_t n = p0.n + p1.n;
+               u32** d_windows, int groups = 1, const MsmExtra* extra = nullptr) {
+  size_t n = p0.n + p1.n + (extra ? 2 : 0);
   hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan);
   if (e != hipSuccess) return fail(ctx, BP_E_ARG, "msm plan (n too large?)", e);
   MsmWorkspace ws{};
@@ -205,7 +213,7 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
   CHK(reserve(ctx, S_SEG_GROUPS, plan->seg_group_bytes, &p)); ws.seg_groups = (u32*)p;
   CHK(reserve(ctx, S_WINDOWS, plan->win_bytes, &p)); ws.windows = (u32*)p;
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  e = msm_run(curve, p0, p1, *plan, ws, ctx->stream, ctx->ev[2], ctx->ev[3]);
+  e = msm_run(curve, p0, p1, extra, *plan, ws, ctx->stream, ctx->ev[2], ctx->ev[3]);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "msm_run", e);
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   *d_windows = ws.windows;
@@ -283,6 +291,7 @@ void bp_shutdown(bp_ctx* ctx) {
   for (auto& b : ctx->buf)
     if (b.p) (void)hipFree(b.p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->ipa_cache) (void)hipFree(ctx->ipa_cache);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -703,14 +712,138 @@ int bp_normalize_batch(bp_ctx* ctx, int curve, const uint64_t* xyz, size_t n, ui
 
 // ---- IPA session -----------------------------------------------------------------
 
+namespace {
+
+// Everything a session owns on the device lives in one block, so a prove costs one
+// allocation; a freed block is parked on the context for the next session.
+struct IpaLayout {
+  size_t gx, gy, ginf, hx, hy, hinf, a, b, cg, ch, eg, eh, u, dots, total;
+};
+
+IpaLayout ipa_layout(size_t n, bool has_h, bool owns_gens) {
+  IpaLayout l{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return at;
+  };
+  if (owns_gens) {
+    l.gx = take(n * 32); l.gy = take(n * 32); l.ginf = take(n);
+    if (has_h) { l.hx = take(n * 32); l.hy = take(n * 32); l.hinf = take(n); }
+  }
+  l.a = take(n * 32); l.b = take(n * 32);
+  l.cg = take(n * 32); l.eg = take(n * 32);
+  if (has_h) { l.ch = take(n * 32); l.eh = take(n * 32); }
+  l.u = take(64);
+  l.dots = take((size_t)2 * (kDotBlocks + 1) * 32);
+  l.total = off;
+  return l;
+}
+
+int ipa_take_block(bp_ctx* ctx, size_t bytes, void** out, size_t* cap) {
+  if (ctx->ipa_cache && ctx->ipa_cache_bytes >= bytes) {
+    *out = ctx->ipa_cache;
+    *cap = ctx->ipa_cache_bytes;
+    ctx->ipa_cache = nullptr;
+    ctx->ipa_cache_bytes = 0;
+    return BP_OK;
+  }
+  HIPCHK(ctx, hipMalloc(out, bytes));
+  *cap = bytes;
+  return BP_OK;
+}
+
+void ipa_release_block(bp_ctx* ctx, void* block, size_t cap) {
+  if (!block) return;
+  if (!ctx->ipa_cache) {
+    ctx->ipa_cache = block;
+    ctx->ipa_cache_bytes = cap;
+    return;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  if (cap > ctx->ipa_cache_bytes) {
+    (void)hipFree(ctx->ipa_cache);
+    ctx->ipa_cache = block;
+    ctx->ipa_cache_bytes = cap;
+  } else {
+    (void)hipFree(block);
+  }
+}
+
+int ipa_begin_common(bp_ctx* ctx, int curve, int variant, const bp_bases* res, size_t g_off, size_t h_off,
+                     const uint64_t* gx, const uint64_t* gy, const uint8_t* ginf, const uint64_t* hx,
+                     const uint64_t* hy, const uint8_t* hinf, const uint64_t* a, const uint64_t* b, size_t n,
+                     bp_ipa** out) {
+  bp_ipa* s = new (std::nothrow) bp_ipa();
+  if (!s) return fail(ctx, BP_E_OOM, "host allocation");
+  s->ctx = ctx;
+  s->curve = curve;
+  s->variant = variant;
+  s->n = s->n0 = n;
+  const bool has_h = variant == BP_IPA_BULLETPROOF;
+  const IpaLayout l = ipa_layout(n, has_h, res == nullptr);
+  void* blk = nullptr;
+  int rc = ipa_take_block(ctx, l.total, &blk, &s->block_bytes);
+  if (rc != BP_OK) {
+    delete s;
+    return rc;
+  }
+  s->block = blk;
+  char* base = (char*)blk;
+  auto at = [&](size_t off) { return (u32*)(base + off); };
+  s->a = at(l.a); s->b = at(l.b); s->cg = at(l.cg); s->eg = at(l.eg);
+  if (has_h) { s->ch = at(l.ch); s->eh = at(l.eh); }
+  s->u_xy = at(l.u);
+  s->dots = at(l.dots);
+  hipError_t e = hipSuccess;
+  auto put = [&](void* d, const void* h, size_t bytes) {
+    if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream);
+  };
+  if (res) {
+    s->gx = res->x + g_off * 8; s->gy = res->y + g_off * 8; s->ginf = res->inf + g_off;
+    if (has_h) { s->hx = res->x + h_off * 8; s->hy = res->y + h_off * 8; s->hinf = res->inf + h_off; }
+  } else {
+    u32 *dgx = at(l.gx), *dgy = at(l.gy);
+    uint8_t* dgi = (uint8_t*)(base + l.ginf);
+    s->gx = dgx; s->gy = dgy; s->ginf = dgi;
+    put(dgx, gx, n * 32); put(dgy, gy, n * 32);
+    if (e == hipSuccess) e = ginf ? hipMemcpyAsync(dgi, ginf, n, hipMemcpyHostToDevice, ctx->stream) : hipMemsetAsync(dgi, 0, n, ctx->stream);
+    if (has_h) {
+      u32 *dhx = at(l.hx), *dhy = at(l.hy);
+      uint8_t* dhi = (uint8_t*)(base + l.hinf);
+      s->hx = dhx; s->hy = dhy; s->hinf = dhi;
+      put(dhx, hx, n * 32); put(dhy, hy, n * 32);
+      if (e == hipSuccess) e = hinf ? hipMemcpyAsync(dhi, hinf, n, hipMemcpyHostToDevice, ctx->stream) : hipMemsetAsync(dhi, 0, n, ctx->stream);
+    }
+  }
+  put(s->a, a, n * 32); put(s->b, b, n * 32);
+  if (e == hipSuccess) e = launch_fill_one(curve, s->cg, n, ctx->stream);
+  if (e == hipSuccess && has_h) e = launch_fill_one(curve, s->ch, n, ctx->stream);
+  // the host arrays may be reused by the caller as soon as this returns
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    int code = fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "bp_ipa_begin", e);
+    ipa_release_block(ctx, s->block, s->block_bytes);
+    delete s;
+    return code;
+  }
+  *out = s;
+  return BP_OK;
+}
+
+}  // namespace
+
 void bp_ipa_free(bp_ipa* s) {
   if (!s) return;
   Guard g(s->ctx);
-  (void)hipStreamSynchronize(s->ctx->stream);
-  void* ptrs[] = {s->gx, s->gy, s->ginf, s->hx, s->hy, s->hinf, s->a, s->b, s->cg, s->ch, s->eg,
-                  s->eh, s->fgx, s->fgy, s->fginf, s->fhx, s->fhy, s->fhinf};
+  void* ptrs[] = {s->fgx, s->fgy, s->fginf, s->fhx, s->fhy, s->fhinf};
+  bool any = false;
+  for (void* p : ptrs) any = any || p;
+  if (any) (void)hipStreamSynchronize(s->ctx->stream);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  ipa_release_block(s->ctx, s->block, s->block_bytes);
   delete s;
 }
 
@@ -723,44 +856,46 @@ int bp_ipa_begin(bp_ctx* ctx, int curve, int variant, const uint64_t* gx, const 
   if (n == 0 || (n & (n - 1))) return fail(ctx, BP_E_ARG, "bp_ipa_begin: n must be a power of two");
   if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
   Guard g(ctx);
-  bp_ipa* s = new (std::nothrow) bp_ipa();
-  if (!s) return fail(ctx, BP_E_OOM, "host allocation");
-  s->ctx = ctx;
-  s->curve = curve;
-  s->variant = variant;
-  s->n = s->n0 = n;
-  bool has_h = variant == BP_IPA_BULLETPROOF;
-  hipError_t e = hipSuccess;
-  auto alloc = [&](void** p, size_t bytes) {
-    if (e == hipSuccess) e = hipMalloc(p, bytes);
-  };
-  alloc((void**)&s->gx, n * 32); alloc((void**)&s->gy, n * 32); alloc((void**)&s->ginf, n);
-  alloc((void**)&s->a, n * 32); alloc((void**)&s->b, n * 32);
-  alloc((void**)&s->cg, n * 32); alloc((void**)&s->eg, n * 32);
-  if (has_h) {
-    alloc((void**)&s->hx, n * 32); alloc((void**)&s->hy, n * 32); alloc((void**)&s->hinf, n);
-    alloc((void**)&s->ch, n * 32); alloc((void**)&s->eh, n * 32);
-  }
-  if (e == hipSuccess) e = launch_fill_one(curve, s->cg, n, ctx->stream);
-  if (e == hipSuccess && has_h) e = launch_fill_one(curve, s->ch, n, ctx->stream);
-  auto put = [&](void* d, const void* h, size_t bytes) {
-    if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream);
-  };
-  put(s->gx, gx, n * 32); put(s->gy, gy, n * 32);
-  if (e == hipSuccess) e = ginf ? hipMemcpyAsync(s->ginf, ginf, n, hipMemcpyHostToDevice, ctx->stream) : hipMemsetAsync(s->ginf, 0, n, ctx->stream);
-  put(s->a, a, n * 32); put(s->b, b, n * 32);
-  if (has_h) {
-    put(s->hx, hx, n * 32); put(s->hy, hy, n * 32);
-    if (e == hipSuccess) e = hinf ? hipMemcpyAsync(s->hinf, hinf, n, hipMemcpyHostToDevice, ctx->stream) : hipMemsetAsync(s->hinf, 0, n, ctx->stream);
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) {
-    int code = fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "bp_ipa_begin", e);
-    g.lk.unlock();
-    bp_ipa_free(s);
-    return code;
-  }
-  *out = s;
+  return ipa_begin_common(ctx, curve, variant, nullptr, 0, 0, gx, gy, ginf, hx, hy, hinf, a, b, n, out);
+}
+
+int bp_ipa_begin_resident(bp_ctx* ctx, const bp_bases* bases, int variant, size_t g_offset, size_t h_offset,
+                          const uint64_t* a, const uint64_t* b, size_t n, bp_ipa** out) {
+  if (!ctx || !out || !bases || !a || !b) return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident: bases belong to another context");
+  if (variant != BP_IPA_BULLETPROOF && variant != BP_IPA_POLYCOMMIT) return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident: bad variant");
+  if (n == 0 || (n & (n - 1))) return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident: n must be a power of two");
+  if (g_offset > bases->n || n > bases->n - g_offset) return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident: g range out of bounds");
+  if (variant == BP_IPA_BULLETPROOF && (h_offset > bases->n || n > bases->n - h_offset))
+    return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident: h range out of bounds");
+  Guard g(ctx);
+  return ipa_begin_common(ctx, bases->curve, variant, bases, g_offset, h_offset, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, a, b, n, out);
+}
+
+int bp_ipa_scale_h(bp_ipa* s, const uint64_t* scale) {
+  if (!s || !scale) return BP_E_ARG;
+  bp_ctx* ctx = s->ctx;
+  if (s->variant != BP_IPA_BULLETPROOF) return fail(ctx, BP_E_ARG, "bp_ipa_scale_h: session has no H vector");
+  if (s->n != s->n0) return fail(ctx, BP_E_STATE, "bp_ipa_scale_h: only before the first fold");
+  Guard g(ctx);
+  // ch *= scale: from here on the session behaves as if H_i had been scale_i * H_i
+  HIPCHK(ctx, hipMemcpyAsync(s->eh, scale, s->n0 * 32, hipMemcpyHostToDevice, ctx->stream));
+  hipError_t e = launch_vec_op(s->curve, BP_VEC_HADAMARD, s->ch, s->eh, FeArg{}, s->n0, s->ch, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "bp_ipa_scale_h", e);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_ipa_set_u(bp_ipa* s, const uint64_t u_xy[8]) {
+  if (!s) return BP_E_ARG;
+  bp_ctx* ctx = s->ctx;
+  Guard g(ctx);
+  s->has_u = false;
+  if (!u_xy) return BP_OK;
+  HIPCHK(ctx, hipMemcpyAsync(s->u_xy, u_xy, 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  s->has_u = true;
   return BP_OK;
 }
 
@@ -774,12 +909,20 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
   const size_t h = s->n / 2, n0 = s->n0;
   const bool has_h = s->variant == BP_IPA_BULLETPROOF;
   const u32 *a_lo = s->a, *a_hi = s->a + h * 8, *b_lo = s->b, *b_hi = s->b + h * 8;
-  hipError_t e = launch_ipa_scalars(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, n0, h, s->eg, s->eh,
-                                    ctx->stream);
+  // c_l = <a_lo, b_hi>, c_r = <a_hi, b_lo> (src/ipa/mod.rs:42,58); they stay on the device as
+  // the scalars of u when one is set
+  u32* part_l = s->dots;
+  u32* part_r = part_l + (size_t)(kDotBlocks + 1) * 8;
+  u32 *d_cl = part_l + (size_t)kDotBlocks * 8, *d_cr = part_r + (size_t)kDotBlocks * 8;
+  hipError_t e = launch_inner_product(s->curve, a_lo, b_hi, h, part_l, d_cl, ctx->stream);
+  if (e == hipSuccess) e = launch_inner_product(s->curve, a_hi, b_lo, h, part_r, d_cr, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "inner_product", e);
+  e = launch_ipa_scalars(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, n0, h, s->eg, s->eh, ctx->stream);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_scalars", e);
   // One pass computes both cross terms: group 0 = L, group 1 = R.
   //   L: G_hi with a_lo, H_lo with b_hi (src/ipa/mod.rs:44-54); R: G_lo with a_hi, H_hi with b_lo (:60-70)
   //   poly-commit: L = <g_hi, a_lo>, R = <g_lo, a_hi> (src/poly_commit/mod.rs:78,83)
+  //   with u set: L += c_l*u, R += c_r*u (src/ipa/mod.rs:43,59; src/poly_commit/mod.rs:80,85)
   MsmPart pg{s->gx, s->gy, s->ginf, s->eg, n0};
   pg.sel_half = h; pg.group_hi = 0; pg.group_lo = 1;
   MsmPart ph{nullptr, nullptr, nullptr, nullptr, 0};
@@ -787,18 +930,10 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
     ph = MsmPart{s->hx, s->hy, s->hinf, s->eh, n0};
     ph.sel_half = h; ph.group_lo = 0; ph.group_hi = 1;
   }
+  MsmExtra extra{{s->u_xy, s->u_xy}, {d_cl, d_cr}};
   MsmPlan plan;
   u32* d_win = nullptr;
-  CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2));
-  // c_l = <a_lo, b_hi>, c_r = <a_hi, b_lo> (src/ipa/mod.rs:42,58)
-  void* part;
-  CHK(reserve(ctx, S_SMALL, (size_t)2 * (kDotBlocks + 1) * 32, &part));
-  u32* part_l = (u32*)part;
-  u32* part_r = part_l + (size_t)(kDotBlocks + 1) * 8;
-  u32 *d_cl = part_l + (size_t)kDotBlocks * 8, *d_cr = part_r + (size_t)kDotBlocks * 8;
-  e = launch_inner_product(s->curve, a_lo, b_hi, h, part_l, d_cl, ctx->stream);
-  if (e == hipSuccess) e = launch_inner_product(s->curve, a_hi, b_lo, h, part_r, d_cr, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "inner_product", e);
+  CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2, s->has_u ? &extra : nullptr));
   CHK(reserve_pinned(ctx, plan.win_bytes + 64));
   char* host = (char*)ctx->pinned;
   HIPCHK(ctx, hipMemcpyAsync(host, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -133,10 +133,18 @@ struct MsmWorkspace {
   u32* windows;       // XYZZ AoS: W * 32 u32
 };
 
+// Two-group split plans only: one more (point, scalar) per group, both read from device memory
+// when the digits kernel runs (so a scalar may be produced by a kernel queued just before).
+// The plan's n_total counts them.
+struct MsmExtra {
+  const u32* xy[2];  // affine x|y, 16 u32, not the identity; extra e goes to group e
+  const u32* s[2];   // Montgomery-form scalar, 8 u32
+};
+
 // Runs digits -> sort -> bucket accumulation -> bucket reduction; leaves W window
 // sums (XYZZ, 32 u32 each) in ws.windows.  ev_acc0/ev_acc1 (optional) bracket the
 // accumulation kernel.
-hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPlan& plan,
+hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExtra* extra, const MsmPlan& plan,
                    const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1);
 // sums n_parts arrays of n_windows XYZZ points window by window into out (n_windows XYZZ)
 hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int n_windows, u32* out,

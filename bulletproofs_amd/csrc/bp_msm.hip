@@ -137,6 +137,11 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
 struct DigitGroups {
   u32 half0, half1;
   u32 lo0, hi0, lo1, hi1;
+  // n_extra = 2: one more point per group after the two parts, extra e in group e; its
+  // coordinates (x|y, 16 u32) and scalar are read from device memory
+  u32 n_extra;
+  const u32* extra_xy[2];
+  const u32* extra_s[2];
 };
 
 template <class C>
@@ -150,9 +155,11 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
                                                 const u32* __restrict__ y1, u32* __restrict__ packed,
                                                 DigitGroups sel) {
   using Fr = typename C::Fr;
-  size_t n = n0 + n1;
+  const size_t n01 = n0 + n1;
+  const size_t n = n01 + sel.n_extra;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const bool is_extra = i >= n01;
   // Output group of this point and its position inside a window's slice of the entry
   // table.  Positions put group 0 before group 1, so that after the stable sort on the
   // bucket number the entries of one (bucket, window, group) are still contiguous.
@@ -161,7 +168,11 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
   {
     const bool second = i >= n0;
     const u32 half_sel = second ? sel.half1 : sel.half0;
-    if (half_sel == 0) {
+    const size_t gsize = n01 / 2 + (sel.n_extra ? 1 : 0);  // positions per group in split mode
+    if (is_extra) {
+      grp = (u32)(i - n01);
+      pos = (size_t)grp * gsize + n01 / 2;
+    } else if (half_sel == 0) {
       grp = second ? sel.lo1 : sel.lo0;
       pos = i;
     } else {
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
       size_t q = li / (2 * (size_t)half_sel), r = li % (2 * (size_t)half_sel);
       bool up = r >= half_sel;
       grp = up ? (second ? sel.hi1 : sel.hi0) : (second ? sel.lo1 : sel.lo0);
-      pos = (size_t)grp * (n / 2) + (second ? n0 / 2 : 0) + q * half_sel + (up ? r - half_sel : r);
+      pos = (size_t)grp * gsize + (second ? n0 / 2 : 0) + q * half_sel + (up ? r - half_sel : r);
     }
   }
   const u32 wbase = grp * (u32)n_windows;
@@ -179,11 +190,16 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
   {
     const u32* px = i < n0 ? x0 + i * 8 : x1 + (i - n0) * 8;
     const u32* py = i < n0 ? y0 + i * 8 : y1 + (i - n0) * 8;
+    if (is_extra) {
+      px = sel.extra_xy[i - n01];
+      py = px + 8;
+    }
     fe_store(packed + i * 16, fe_load(px));
     fe_store(packed + i * 16 + 8, fe_load(py));
   }
   const u32* sp = i < n0 ? s0 + i * 8 : s1 + (i - n0) * 8;
-  bool is_inf = i < n0 ? (inf0 && inf0[i]) : (inf1 && inf1[i - n0]);
+  if (is_extra) sp = sel.extra_s[i - n01];
+  bool is_inf = is_extra ? false : (i < n0 ? (inf0 && inf0[i]) : (inf1 && inf1[i - n0]));
   Fe k = fe_from_mont<Fr>(fe_load(sp));
   // |k| <= r/2: use r - k with the point negated when that is the smaller value
   u32 flip = 0;
@@ -528,7 +544,7 @@ hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int
   return hipGetLastError();
 }
 
-hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPlan& plan,
+hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExtra* extra, const MsmPlan& plan,
                    const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
   const size_t n = plan.n_total;
   const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
@@ -537,8 +553,20 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmPla
     // all windows = identity (zz = 0)
     return hipMemsetAsync(ws.windows, 0, plan.win_bytes, st);
   }
-  DigitGroups sel{(u32)p0.sel_half, (u32)p1.sel_half, p0.group_lo, p0.group_hi, p1.group_lo, p1.group_hi};
-  if (plan.groups == 1) sel = DigitGroups{0, 0, 0, 0, 0, 0};
+  DigitGroups sel{(u32)p0.sel_half, (u32)p1.sel_half, p0.group_lo, p0.group_hi, p1.group_lo, p1.group_hi, 0,
+                  {nullptr, nullptr}, {nullptr, nullptr}};
+  if (plan.groups == 1) sel = DigitGroups{0, 0, 0, 0, 0, 0, 0, {nullptr, nullptr}, {nullptr, nullptr}};
+  if (extra) {
+    // one extra point per group, split parts only
+    if (plan.groups != 2 || !p0.sel_half || (p1.n && !p1.sel_half) || n != p0.n + p1.n + 2) return hipErrorInvalidValue;
+    sel.n_extra = 2;
+    for (int e = 0; e < 2; e++) {
+      sel.extra_xy[e] = extra->xy[e];
+      sel.extra_s[e] = extra->s[e];
+    }
+  } else if (n != p0.n + p1.n) {
+    return hipErrorInvalidValue;
+  }
   // split parts must tile evenly, and split and whole parts cannot be mixed
   if (plan.groups == 2) {
     if ((p0.sel_half != 0) != (p1.sel_half != 0) && p0.n && p1.n) return hipErrorInvalidValue;

@@ -215,14 +215,46 @@ struct Ipa {
     bp_ipa* s = nullptr;
     check(ctx, bp_ipa_begin(ctx, CURVE, BP_IPA_BULLETPROOF, gx.data(), gy.data(), gi.data(), hx.data(), hy.data(),
                             hi.data(), a[0].l, b[0].l, n, &s), "bp_ipa_begin");
+    return prove_session(ctx, s, crs.u, t);
+  }
+
+  // The same loop over generators that are already resident on the GPU (bases[g_off..),
+  // bases[h_off..)), optionally with H_i scaled by h_scale[i] (the hs' of
+  // src/range/aggregate.rs:148-153 without materialising them).
+  static IpaProof prove_resident(bp_ctx* ctx, const bp_bases* bases, size_t g_off, size_t h_off, const Scalar* h_scale,
+                                 const Affine& u, const std::vector<Scalar>& a, const std::vector<Scalar>& b,
+                                 Transcript& t) {
+    bp_ipa* s = nullptr;
+    check(ctx, bp_ipa_begin_resident(ctx, bases, BP_IPA_BULLETPROOF, g_off, h_off, a[0].l, b[0].l, a.size(), &s),
+          "bp_ipa_begin_resident");
+    if (h_scale) {
+      int rc = bp_ipa_scale_h(s, h_scale[0].l);
+      if (rc != BP_OK) { bp_ipa_free(s); check(ctx, rc, "bp_ipa_scale_h"); }
+    }
+    return prove_session(ctx, s, u, t);
+  }
+
+  // takes ownership of the session
+  static IpaProof prove_session(bp_ctx* ctx, bp_ipa* s, const Affine& u_aff, Transcript& t) {
     IpaProof proof;
-    HXyzz u = P::lift(crs.u);
+    HXyzz u = P::lift(u_aff);
     try {
+      // u*c_l and u*c_r ride in the device pass (two 256-bit scalar multiplications per
+      // round would otherwise be done here on one host core)
+      const bool u_on_device = !u_aff.inf;
+      if (u_on_device) {
+        uint64_t uxy[8];
+        memcpy(uxy, u_aff.x, 32); memcpy(uxy + 4, u_aff.y, 32);
+        check(ctx, bp_ipa_set_u(s, uxy), "bp_ipa_set_u");
+      }
       while (bp_ipa_len(s) != 1) {
         Projective lm, rm; Scalar cl, cr;
         check(ctx, bp_ipa_round_lr(s, lm.xyz, rm.xyz, cl.l, cr.l), "bp_ipa_round_lr");
-        Projective lr[2] = {P::lower(hx_add<Fq>(P::mul(u, cl), P::lift(lm))),   // :43-55
-                            P::lower(hx_add<Fq>(P::mul(u, cr), P::lift(rm)))};  // :59-71
+        Projective lr[2] = {lm, rm};                                            // :43-55, :59-71
+        if (!u_on_device) {
+          lr[0] = P::lower(hx_add<Fq>(P::mul(u, cl), P::lift(lm)));
+          lr[1] = P::lower(hx_add<Fq>(P::mul(u, cr), P::lift(rm)));
+        }
         t.prover_points(lr, 2);                                                 // :75
         Scalar alpha = t.verifier_scalar();                                     // :77
         Scalar alpha_inv = S::inv(alpha);                                       // :78

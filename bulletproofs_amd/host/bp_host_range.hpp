@@ -137,21 +137,20 @@ struct RangeAggregate {
     check(ctx, bp_vec_op(ctx, CURVE, BP_VEC_AXPY, l0[0].l, s_l[0].l, x.l, n, l[0].l), "axpy");
     check(ctx, bp_vec_op(ctx, CURVE, BP_VEC_AXPY, r0[0].l, r1[0].l, x.l, n, r[0].l), "axpy");
     pr.t_hat = dot(ctx, l, r);                               // Witness::new, :146
-    std::vector<Scalar> y_inv_pows; std::vector<Affine> hsp;
-    hs_prime(ctx, crs, y, y_inv_pows, hsp);                  // :148-153
-    // :155-157 -- the extended statement is computed (over the unscaled hs) although the
-    // prover never sends it; kept so the work matches the reference's prove()
-    Projective p_ext = msm_gh(ctx, crs, l, r);
-    (void)p_ext;
+    // :148-153 -- hs'_i = y^-i h_i is not materialised (N scalar multiplications in the
+    // reference): the IPA session over the resident gs || hs carries y^-i as the initial
+    // coefficient of h_i, which yields the same L, R, a, b.
+    std::vector<Scalar> y_inv_pows(n);
+    Scalar y_inv = S::inv(y);
+    check(ctx, bp_powers(ctx, CURVE, y_inv.l, n, y_inv_pows[0].l), "bp_powers");
+    // :155-157 -- extended_statement.p is updated by the prover but never sent
+    // (src/ipa/mod.rs:94 is its only use), so it is not computed; its c is t_hat.
     Scalar msg[3] = {pr.tao_x, pr.mu, pr.t_hat};
     t.prover_scalars(msg, 3);                                // :159
     // ipa::extended::prove (src/ipa/extended.rs:15-35) over gs, hs', u' = x'*u
     Scalar xe = t.verifier_scalar();
-    typename I::Crs crs2;
-    crs2.gs.assign(crs.ipa.gs.begin(), crs.ipa.gs.begin() + n);
-    crs2.hs = hsp;
-    crs2.u = P::to_affine(P::lower(P::mul(P::lift(crs.ipa.u), xe)));
-    pr.ipa = I::prove(ctx, crs2, l, r, t);                   // :166
+    Affine u2 = P::to_affine(P::lower(P::mul(P::lift(crs.ipa.u), xe)));
+    pr.ipa = I::prove_resident(ctx, crs.gh, 0, n, y_inv_pows.data(), u2, l, r, t);  // :166
     return pr;
   }
 

@@ -182,11 +182,31 @@ int bp_s_vector_dev(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* 
  * (src/ipa/mod.rs:33-95) or poly_commit::prove (src/poly_commit/mod.rs:69-105;
  * pass hs = NULL).  n must be a power of two >= 1.  The transcript stays with
  * the caller: round_lr returns the MSM parts of L and R and the two cross
- * inner products; the caller adds u*c (and h*l_j), derives the challenge and
- * passes it (and its inverse) to round_fold. */
+ * inner products; the caller adds u*c (unless bp_ipa_set_u was called) and
+ * h*l_j, derives the challenge and passes it (and its inverse) to round_fold.
+ * The generator vectors are not folded round by round (src/ipa/mod.rs:80-83 is
+ * carried as one coefficient per original generator); bp_ipa_read materialises
+ * the folded generators on request. */
 int bp_ipa_begin(bp_ctx* ctx, int curve, int variant, const uint64_t* gx, const uint64_t* gy,
                  const uint8_t* ginf, const uint64_t* hx, const uint64_t* hy, const uint8_t* hinf,
                  const uint64_t* a, const uint64_t* b, size_t n, bp_ipa** out);
+/* As bp_ipa_begin with the generators taken from a registered base set, not copied:
+ * G = bases[g_offset, g_offset+n), H = bases[h_offset, h_offset+n) (h_offset ignored
+ * for BP_IPA_POLYCOMMIT).  Replaces the per-proof `crs.gs[0..n].to_vec()` /
+ * `crs.hs[0..n].to_vec()` of src/ipa/mod.rs:29-30.  The base set must outlive the
+ * session. */
+int bp_ipa_begin_resident(bp_ctx* ctx, const bp_bases* bases, int variant, size_t g_offset,
+                          size_t h_offset, const uint64_t* a, const uint64_t* b, size_t n,
+                          bp_ipa** out);
+/* From now on the session behaves as if H_i had been scale[i] * H_i (n host scalars):
+ * the hs' = y^-i * h_i that src/range/aggregate.rs:148-153 materialises with n scalar
+ * multiplications (create_hs_prime, src/range/utils.rs:22-29) before ipa::extended::prove.
+ * BP_IPA_BULLETPROOF sessions, before the first fold only (BP_E_STATE otherwise). */
+int bp_ipa_scale_h(bp_ipa* s, const uint64_t* scale);
+/* Sets the point u (affine x|y, 8 u64, not the identity; NULL clears it).  With u set,
+ * bp_ipa_round_lr returns L = c_l*u + <..>, R = c_r*u + <..> complete
+ * (src/ipa/mod.rs:43,59; src/poly_commit/mod.rs:80,85) in the same device pass. */
+int bp_ipa_set_u(bp_ipa* s, const uint64_t u_xy[8]);
 int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t c_l[4],
                     uint64_t c_r[4]);
 int bp_ipa_round_fold(bp_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]);

@@ -427,6 +427,52 @@ def test_ipa_final_generator_property(ctx, coracle, variant):
     s.free()
 
 
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_ipa_resident_scaled_with_u(ctx, c, variant):
+    """generators from a registered base set, H scaled by y^-i, u folded into L and R:
+    every round equals the oracle's ipa round over (gs, hs' = y^-i hs) plus c*u
+    (src/range/aggregate.rs:148-166, src/ipa/mod.rs:40-73)"""
+    from bulletproofs_amd import BpError
+
+    n, k = 32, 5
+    g, h, a, b, ch = ipa_inputs(c, n, 4242 + variant)
+    u = o.scalar_mul(987654321, c.g, c)
+    yinv = pow(31337, -1, c.n)
+    scale = [pow(yinv, i, c.n) for i in range(n)]
+    hsp = o.scale_points(h, scale, c) if variant == 0 else None
+    bases = ctx.register_bases(c.id, o.pack_points(g + h, c))
+    s = ctx.ipa_begin_resident(bases, variant, 0, n, o.pack_field(a, c.n), o.pack_field(b, c.n))
+    if variant == 0:
+        s.scale_h(o.pack_field(scale, c.n))
+    else:
+        with pytest.raises(BpError):
+            s.scale_h(o.pack_field(scale, c.n))
+    ux, uy, _ = o.pack_points([u], c)
+    s.set_u(np.concatenate([ux[0], uy[0]]))
+    gs_cur, hs_cur, a_cur, b_cur = list(g), (list(hsp) if hsp else list(h)), list(a), list(b)
+    for j in range(k):
+        L, R, cl, cr = s.round_lr()
+        eL, eR, ecl, ecr = o.ipa_round_lr(variant, gs_cur, hs_cur, a_cur, b_cur, c)
+        eL = o.add(eL, o.scalar_mul(ecl, u, c), c)
+        eR = o.add(eR, o.scalar_mul(ecr, u, c), c)
+        assert xyz_to_affine(L, c) == eL and xyz_to_affine(R, c) == eR, j
+        assert o.unpack_field(cl, c.n)[0] == ecl and o.unpack_field(cr, c.n)[0] == ecr
+        x = ch[j]
+        if j == 1 and variant == 0:
+            with pytest.raises(BpError):
+                s.scale_h(o.pack_field(scale, c.n))  # only before the first fold
+        s.round_fold(o.pack_field([x], c.n), o.pack_field([pow(x, -1, c.n)], c.n))
+        gs_cur, hs_cur, a_cur, b_cur = o.ipa_round_fold(variant, gs_cur, hs_cur, a_cur, b_cur, x, c)
+    G, H, A, B = s.read()
+    assert o.unpack_points(*G, c) == gs_cur
+    if variant == 0:
+        assert o.unpack_points(*H, c) == hs_cur
+    assert o.unpack_field(A, c.n) == a_cur and o.unpack_field(B, c.n) == b_cur
+    s.free()
+    bases.free()
+
+
 # ---- error behaviour -----------------------------------------------------------------------
 
 
