@@ -40,7 +40,15 @@ gamma[:, 3] &= np.uint64((1 << 63) - 1)
 host_mirror.range_aggregate_roundtrip(ctx, bp.SECP256K1, gs, hs, ugh, values, gamma, n_bits, SEED, SEED + 1, reps=1)
 res = host_mirror.range_aggregate_roundtrip(ctx, bp.SECP256K1, gs, hs, ugh, values, gamma, n_bits, SEED, SEED + 1, reps=5)
 assert res["ok"]
-print(json.dumps({"metric": "aggregated 64-bit range proofs/sec", "m": m, "n_bits": n_bits, "N": n,
-                  "prove_ms": res["prove_ms"], "verify_ms": res["verify_ms"],
-                  "prove_per_s": 1e3 / res["prove_ms"], "verify_per_s": 1e3 / res["verify_ms"], "n_gpus": 1,
-                  "note": "seeded transcript stand-in; host buffers in, proof out"}))
+out = {"metric": "aggregated 64-bit range proofs/sec", "m": m, "n_bits": n_bits, "N": n,
+       "prove_ms": res["prove_ms"], "verify_ms": res["verify_ms"],
+       "prove_per_s": 1e3 / res["prove_ms"], "verify_per_s": 1e3 / res["verify_ms"], "n_gpus": 1,
+       "note": "seeded transcript stand-in; host buffers in, proof out; *_ms and *_per_s are one proof at a time on "
+               "one context, concurrent[] is W host threads with one context each on the same GPU"}
+workers = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 4, 8]
+out["concurrent"] = []
+for w in workers:
+    thr = host_mirror.range_aggregate_throughput(0, bp.SECP256K1, gs, hs, ugh, values, gamma, n_bits, w, 8, SEED, SEED + 1)
+    assert thr["ok"]
+    out["concurrent"].append({"workers": w, "prove_per_s": thr["prove_per_s"], "verify_per_s": thr["verify_per_s"]})
+print(json.dumps(out))

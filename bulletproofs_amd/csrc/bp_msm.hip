@@ -112,6 +112,16 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   // there are still tens of thousands of lanes
   size_t t = p.entries / 65536;
   p.chunk = (u32)(t < 4 ? 4 : (t > 32 ? 32 : t));
+  // small problems are a dependent chain of `chunk` mixed additions (10 M each) and then one
+  // full addition (14 M) per chunk of the bucket: for E entries per bucket the chain is
+  // shortest near chunk = sqrt(1.4 E)
+  {
+    size_t per_bucket = n_total / (size_t)groups / p.n_buckets + 1;
+    u32 bal = 1;
+    while ((size_t)bal * bal * 10 < per_bucket * 14) bal++;
+    if (getenv("BP_MSM_CHUNK")) bal = (u32)atoi(getenv("BP_MSM_CHUNK"));
+    if (bal > p.chunk && bal <= 32) p.chunk = bal;
+  }
   // very large inputs: about 2^21 chunks are plenty of lanes, and longer chunks keep the
   // number of partial sums per bucket small
   if ((p.entries >> 21) > p.chunk) p.chunk = (u32)((p.entries >> 21) > 4096 ? 4096 : (p.entries >> 21));

@@ -9,6 +9,10 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <chrono>
 #include <stdexcept>
 #include <unordered_map>
 #include <vector>
@@ -41,6 +45,18 @@ struct AffineHash {
 };
 struct Projective {  // normalised Jacobian as returned by the ABI
   uint64_t xyz[12];
+};
+
+// BP_HOST_TRACE=1 prints the wall time between marks of a driver to stderr
+struct PhaseTrace {
+  bool on = getenv("BP_HOST_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (!on) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[bp trace] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
+  }
 };
 
 inline void check(bp_ctx* ctx, int rc, const char* what) {

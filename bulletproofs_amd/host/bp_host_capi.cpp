@@ -143,7 +143,11 @@ int bph_ipa_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_t
 }  // extern "C"
 
 // ---- aggregated range proof round trip ------------------------------------------------
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include "bp_host_range.hpp"
 
@@ -233,9 +237,117 @@ int range_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const u
   return 0;
 }
 
+// `workers` host threads, each with its own context (stream + workspace) on one GPU, prove
+// and then verify `reps` proofs each at the same time: a single proof is a chain of small
+// dependent launches that leaves most of the GPU idle, so independent proofs overlap.
+template <class Fq, class Fr, int CURVE>
+int range_throughput(int device, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx, const uint64_t* hy,
+                     const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma, size_t m, unsigned n_bits,
+                     uint64_t seed_rand, uint64_t seed_chal, int workers, int reps, double* prove_wall_ms,
+                     double* verify_wall_ms, int* ok) {
+  using R = RangeAggregate<Fq, Fr, CURVE>;
+  using PO = PointOps<Fq, Fr>;
+  const size_t n = (size_t)n_bits * m;
+  std::vector<uint64_t> vals(values, values + m);
+  std::vector<Scalar> gam = unpack_s(gamma, m);
+  auto pt = [&](int k) { Affine a; memcpy(a.x, ugh_xy + 8 * k, 32); memcpy(a.y, ugh_xy + 8 * k + 4, 32); a.inf = 0; return a; };
+  const Affine u = pt(0), g = pt(1), h = pt(2);
+  std::vector<Projective> vcom(m);
+  for (size_t j = 0; j < m; j++)
+    vcom[j] = PO::lower(hx_add<Fq>(PO::mul(PO::lift(g), R::from_u64(vals[j])), PO::mul(PO::lift(h), gam[j])));
+  std::mutex mu;
+  std::condition_variable cv;
+  int phase_ready[3] = {0, 0, 0};  // workers that reached: set-up done, proving done, verifying done
+  std::atomic<int> failures{0};
+  using clock = std::chrono::steady_clock;
+  std::vector<clock::time_point> p0(workers), p1(workers), v0(workers), v1(workers);
+  auto rendezvous = [&](int phase) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (++phase_ready[phase] == workers) cv.notify_all();
+    cv.wait(lk, [&] { return phase_ready[phase] >= workers; });
+  };
+  auto body = [&](int w) {
+    bp_ctx* ctx = nullptr;
+    bool reached[3] = {false, false, false};
+    try {
+      if (bp_init(device, &ctx) != BP_OK) throw std::runtime_error("bp_init");
+      typename R::Crs crs;
+      crs.ipa.gs = unpack(gx, gy, nullptr, n);
+      crs.ipa.hs = unpack(hx, hy, nullptr, n);
+      crs.ipa.u = u; crs.g = g; crs.h = h;
+      R::register_bases(ctx, crs, n);
+      std::vector<RangeProof> proofs(reps);
+      {  // warm-up: grows the context's workspace
+        SeededTranscript<Fr> t(seed_chal + w);
+        SeededRandom<Fr> rng(seed_rand + w);
+        proofs[0] = R::prove(ctx, crs, vals, gam, n_bits, t, rng);
+        SeededTranscript<Fr> t2(seed_chal + w);
+        SeededRandom<Fr> vrng(seed_rand ^ 0x5EEDull);
+        if (!is_zero(R::verify_aux(ctx, crs, vcom, n_bits, proofs[0], t2, vrng).execute())) failures++;
+      }
+      reached[0] = true; rendezvous(0);
+      p0[w] = clock::now();
+      for (int r = 0; r < reps; r++) {
+        SeededTranscript<Fr> t(seed_chal + w + 1000 * r);
+        SeededRandom<Fr> rng(seed_rand + w + 1000 * r);
+        proofs[r] = R::prove(ctx, crs, vals, gam, n_bits, t, rng);
+      }
+      p1[w] = clock::now();
+      reached[1] = true; rendezvous(1);
+      v0[w] = clock::now();
+      for (int r = 0; r < reps; r++) {
+        SeededTranscript<Fr> t(seed_chal + w + 1000 * r);
+        SeededRandom<Fr> vrng(seed_rand ^ 0x5EEDull);
+        if (!is_zero(R::verify_aux(ctx, crs, vcom, n_bits, proofs[r], t, vrng).execute())) failures++;
+      }
+      v1[w] = clock::now();
+      reached[2] = true; rendezvous(2);
+      bp_bases_free(crs.gh);
+    } catch (...) {
+      failures++;
+      for (int ph = 0; ph < 3; ph++)
+        if (!reached[ph]) rendezvous(ph);  // never leave the other workers waiting
+    }
+    if (ctx) bp_shutdown(ctx);
+  };
+  std::vector<std::thread> th;
+  for (int w = 0; w < workers; w++) th.emplace_back(body, w);
+  for (auto& t : th) t.join();
+  auto span = [&](std::vector<clock::time_point>& a, std::vector<clock::time_point>& b) {
+    clock::time_point lo = a[0], hi = b[0];
+    for (int w = 1; w < workers; w++) { if (a[w] < lo) lo = a[w]; if (b[w] > hi) hi = b[w]; }
+    return std::chrono::duration<double, std::milli>(hi - lo).count();
+  };
+  *ok = failures.load() == 0;
+  *prove_wall_ms = span(p0, p1);
+  *verify_wall_ms = span(v0, v1);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+// workers x reps aggregated range proofs proved, then verified, concurrently on one GPU
+// (one context per worker thread).  Wall times cover all workers' proving / verifying.
+int bph_range_agg_throughput(int device, int curve, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx,
+                             const uint64_t* hy, const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma,
+                             size_t m, unsigned n_bits, uint64_t seed_rand, uint64_t seed_chal, int workers, int reps,
+                             double* prove_wall_ms, double* verify_wall_ms, int* ok) {
+  if (workers < 1 || workers > 16 || reps < 1) return BP_E_ARG;
+  try {
+    if (curve == BP_SECP256K1)
+      return range_throughput<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(device, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits,
+                                                                     seed_rand, seed_chal, workers, reps, prove_wall_ms,
+                                                                     verify_wall_ms, ok);
+    if (curve == BP_VESTA)
+      return range_throughput<VestaFq, VestaFr, BP_VESTA>(device, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits, seed_rand,
+                                                         seed_chal, workers, reps, prove_wall_ms, verify_wall_ms, ok);
+    return BP_E_CURVE;
+  } catch (const std::exception&) {
+    return BP_E_HIP;
+  }
+}
 
 // Aggregated range proof over m values of n_bits bits (N = m*n_bits a power of two):
 // prove, then verify, `reps` times with identical seeds; averages the wall time of

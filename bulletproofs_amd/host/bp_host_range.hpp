@@ -86,6 +86,7 @@ struct RangeAggregate {
     const size_t m = values.size(), n = (size_t)n_bits * m;
     if (n != crs.n) throw std::invalid_argument("CRS registered for another size");
     const Scalar one = S::one(), zero = S::zero();
+    PhaseTrace tr;
     std::vector<Scalar> a_l(n), a_r(n);                      // :50-64
     for (size_t j = 0; j < m; j++)
       for (unsigned i = 0; i < n_bits; i++) {
@@ -99,8 +100,10 @@ struct RangeAggregate {
     for (auto& v : s_r) v = rng.scalar();
     HXyzz h = P::lift(crs.h), g = P::lift(crs.g);
     RangeProof pr;
+    tr.mark("bits, blinders");
     pr.a = P::lower(hx_add<Fq>(P::mul(h, alpha), P::lift(msm_gh(ctx, crs, a_l, a_r))));   // :81
     pr.s = P::lower(hx_add<Fq>(P::mul(h, rho), P::lift(msm_gh(ctx, crs, s_l, s_r))));     // :82
+    tr.mark("A, S commitments");
     Projective as[2] = {pr.a, pr.s};
     t.prover_points(as, 2);                                  // :85
     Scalar y = t.verifier_scalar(), z = t.verifier_scalar(); // :86
@@ -120,11 +123,13 @@ struct RangeAggregate {
       }
       zpow = S::mul(zpow, z);
     }
+    tr.mark("powers, l/r polynomials");
     Scalar tao1 = rng.scalar(), tao2 = rng.scalar();         // :121-122
     // t(X) = <l(X), r(X)>: t1 = <l0,r1> + <l1,r0>, t2 = <l1,r1>   (:125, src/range/types.rs:98-117)
     Scalar t1 = S::add(dot(ctx, l0, r1), dot(ctx, s_l, r0)), t2 = dot(ctx, s_l, r1);
     pr.tt1 = P::lower(hx_add<Fq>(P::mul(g, t1), P::mul(h, tao1)));  // :126
     pr.tt2 = P::lower(hx_add<Fq>(P::mul(g, t2), P::mul(h, tao2)));  // :127
+    tr.mark("t1, t2, T1, T2");
     Projective tt[2] = {pr.tt1, pr.tt2};
     t.prover_points(tt, 2);                                  // :129
     Scalar x = t.verifier_scalar();                          // :133
@@ -150,7 +155,9 @@ struct RangeAggregate {
     // ipa::extended::prove (src/ipa/extended.rs:15-35) over gs, hs', u' = x'*u
     Scalar xe = t.verifier_scalar();
     Affine u2 = P::to_affine(P::lower(P::mul(P::lift(crs.ipa.u), xe)));
+    tr.mark("l, r, t_hat, y^-i, u'");
     pr.ipa = I::prove_resident(ctx, crs.gh, 0, n, y_inv_pows.data(), u2, l, r, t);  // :166
+    tr.mark("ipa rounds");
     return pr;
   }
 

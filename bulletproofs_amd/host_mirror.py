@@ -87,3 +87,29 @@ def range_aggregate_roundtrip(ctx: Context, curve, gs, hs, ugh_xy, values, gamma
         raise RuntimeError(f"bph_range_agg_roundtrip rc={rc}")
     return dict(A=pts[0], S=pts[1], TT1=pts[2], TT2=pts[3], tao_x=sc[0], mu=sc[1], t_hat=sc[2], a=sc[3], b=sc[4],
                 L=lr[:k, :12], R=lr[:k, 12:], prove_ms=tp.value, verify_ms=tv.value, ok=bool(ok.value))
+
+
+hlib.bph_range_agg_throughput.restype = ci
+hlib.bph_range_agg_throughput.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint64, C.c_uint64, ci, ci,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]
+
+
+def range_aggregate_throughput(device, curve, gs, hs, ugh_xy, values, gamma, n_bits, workers, reps, seed_rand=1, seed_chal=2):
+    """`workers` host threads (one GPU context each) prove and then verify `reps` aggregated
+    range proofs each, concurrently on one GPU.  Returns proofs/s for each phase."""
+    gx, gy, _ = _pts(gs)
+    hx, hy, _ = _pts(hs)
+    values = np.ascontiguousarray(values, dtype=np.uint64)
+    gamma = _f(gamma)
+    m = values.shape[0]
+    n = m * n_bits
+    assert n & (n - 1) == 0 and gx.shape[0] >= n and hx.shape[0] >= n
+    ugh_xy = np.ascontiguousarray(ugh_xy, dtype=np.uint64).reshape(24)
+    tp, tv, ok = C.c_double(), C.c_double(), ci()
+    rc = hlib.bph_range_agg_throughput(device, curve, _p(gx), _p(gy), _p(hx), _p(hy), _p(ugh_xy), _p(values), _p(gamma), m,
+                                       n_bits, seed_rand, seed_chal, workers, reps, C.byref(tp), C.byref(tv), C.byref(ok))
+    if rc:
+        raise RuntimeError(f"bph_range_agg_throughput rc={rc}")
+    total = workers * reps
+    return dict(ok=bool(ok.value), prove_wall_ms=tp.value, verify_wall_ms=tv.value,
+                prove_per_s=total / tp.value * 1e3, verify_per_s=total / tv.value * 1e3)
