@@ -39,6 +39,11 @@ namespace bp {
 
 constexpr u32 kChunkKeyInvalid = 63;  // sort key of the unused tail of the chunk table
 constexpr int kChunkKeyBits = 6;
+// limits of the one-launch front end for small problems (k_small_front)
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallIters = 17;
+constexpr size_t kSmallMaxPoints = (size_t)kSmallThreads * kSmallIters;
+constexpr u32 kSmallMaxBuckets = 4096;
 
 static inline int ilog2_floor(size_t n) {
   int l = 0;
@@ -54,7 +59,6 @@ int msm_choose_window(size_t n) {
   if (l >= 17) return 16;
   if (l >= 14) return 13;
   if (l == 13) return 11;
-  if (l == 12) return 10;
   if (l >= 9) return 8;
   return 4;
 }
@@ -126,6 +130,14 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   // number of partial sums per bucket small
   if ((p.entries >> 21) > p.chunk) p.chunk = (u32)((p.entries >> 21) > 4096 ? 4096 : (p.entries >> 21));
   p.nc_cap = p.entries / p.chunk + nbt + 1;
+  p.small = n_total > 0 && n_total <= kSmallMaxPoints && p.n_buckets <= kSmallMaxBuckets && !getenv("BP_MSM_NO_SMALL");
+  if (p.small) {
+    // every window owns a fixed range of the sorted-entry array and of the chunk table
+    p.cap_w = (u32)(n_total / p.chunk + p.n_buckets + 1);
+    p.nc_cap = (size_t)p.n_windows * p.cap_w;
+    size_t need = (size_t)p.n_windows * n_total * sizeof(u32);
+    if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
+  }
   p.nch_bytes = ((nbt + 2) * sizeof(u32) + 255) & ~(size_t)255;
   p.chunk_sum_bytes = p.nc_cap * 4 * 32;
   tmp = 0;
@@ -262,6 +274,222 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
     if (is_inf) key = invalid;
     keys[(size_t)w * n + pos] = key;
     vals[(size_t)w * n + pos] = val;
+  }
+}
+
+// ---- 1-3 for small problems ---------------------------------------------------------
+// Up to kSmallMaxPoints points: one 1024-lane block per (group, window) does what k_digits,
+// the radix sort, k_bounds, the chunk count/scan and k_chunk_desc do for large inputs --
+// digits of its window, a counting sort in LDS (bucket histogram with LDS atomics whose
+// return value is the entry's rank inside its bucket, block scan, scatter), bucket bounds
+// and the chunk table of its window -- in one launch instead of about forty.  A small MSM
+// is a chain of dependent launches, so the launch count is what it costs.  The order of
+// entries inside a bucket is arbitrary here; the bucket's sum does not depend on it.
+
+// exclusive prefix sum of one value per lane over a 1024-lane block; *total = sum of all
+__device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* wave_sums, u32* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wave_sums[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    for (int w = 0; w < kSmallThreads / 64; w++) {
+      u32 t = wave_sums[w];
+      wave_sums[w] = run;
+      run += t;
+    }
+    wave_sums[kSmallThreads / 64] = run;
+  }
+  __syncthreads();
+  u32 res = wave_sums[wave] + inc - v;
+  *total = wave_sums[kSmallThreads / 64];
+  __syncthreads();
+  return res;
+}
+
+template <class C>
+__global__ __launch_bounds__(1024) void k_small_front(
+    const u32* __restrict__ s0, const uint8_t* __restrict__ inf0, size_t n0, const u32* __restrict__ s1,
+    const uint8_t* __restrict__ inf1, size_t n1, const u32* __restrict__ x0, const u32* __restrict__ y0,
+    const u32* __restrict__ x1, const u32* __restrict__ y1, u32* __restrict__ packed, DigitGroups sel, int c,
+    int group_windows, u32 n_buckets, int wshift, u32 chunk, u32 cap_w, u32* __restrict__ sorted_vals,
+    u32* __restrict__ bucket_start, u32* __restrict__ bucket_end, u32* __restrict__ nch, u32* __restrict__ choff,
+    u32* __restrict__ ckey, u32* __restrict__ cval, u32* __restrict__ desc_b, u32* __restrict__ desc_s,
+    u32* __restrict__ heavy_count) {
+  using Fr = typename C::Fr;
+  __shared__ u32 hist[kSmallMaxBuckets];
+  __shared__ u32 off[kSmallMaxBuckets];
+  __shared__ u32 coff[kSmallMaxBuckets];
+  __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
+  __shared__ u32 thr[8], msk[8];  // window w: carry-in threshold T_w and the mask of the low c*w bits
+  const u32 wid = blockIdx.x;
+  const u32 g = wid / (u32)group_windows, w = wid % (u32)group_windows;
+  const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
+  const u32 half = 1u << (c - 1), mask = (1u << c) - 1;
+  for (u32 b = threadIdx.x; b < n_buckets; b += kSmallThreads) hist[b] = 0;
+  if (threadIdx.x == 0) {
+    // A value's signed digits d_j in (-half, half] below window w represent its low c*w bits
+    // without a carry exactly when those bits are <= T_w = half * sum_{j<w} 2^(c*j).
+    for (int t = 0; t < 8; t++) thr[t] = msk[t] = 0;
+    for (u32 j = 0; j < w; j++) {
+      u32 bit = j * (u32)c + (u32)c - 1;  // position of `half` in digit j
+      if (bit < 256) thr[bit >> 5] |= 1u << (bit & 31);
+    }
+    u32 low = w * (u32)c;
+    for (u32 bit = 0; bit < low && bit < 256; bit++) msk[bit >> 5] |= 1u << (bit & 31);
+    if (wid == 0) *heavy_count = 0;
+  }
+  __syncthreads();
+  u32 my_key[kSmallIters], my_val[kSmallIters], my_rank[kSmallIters];
+  const u32 invalid = n_buckets;
+  const int bit0 = (int)(w * (u32)c), limb = bit0 >> 5, sh = bit0 & 31;
+#pragma unroll
+  for (int it = 0; it < kSmallIters; it++) {
+    my_key[it] = invalid;
+    my_val[it] = 0;
+    my_rank[it] = 0;
+    size_t i = (size_t)it * kSmallThreads + threadIdx.x;
+    if (i >= n) continue;
+    const bool is_extra = i >= n01, second = i >= n0;
+    u32 grp;
+    {
+      const u32 half_sel = second ? sel.half1 : sel.half0;
+      if (is_extra) {
+        grp = (u32)(i - n01);
+      } else if (half_sel == 0) {
+        grp = second ? sel.lo1 : sel.lo0;
+      } else {
+        size_t li = second ? i - n0 : i;
+        bool up = (li % (2 * (size_t)half_sel)) >= half_sel;
+        grp = up ? (second ? sel.hi1 : sel.hi0) : (second ? sel.lo1 : sel.lo0);
+      }
+    }
+    if (grp != g) continue;
+    if (w == 0) {
+      const u32* px = second ? x1 + (i - n0) * 8 : x0 + i * 8;
+      const u32* py = second ? y1 + (i - n0) * 8 : y0 + i * 8;
+      if (is_extra) {
+        px = sel.extra_xy[i - n01];
+        py = px + 8;
+      }
+      fe_store(packed + i * 16, fe_load(px));
+      fe_store(packed + i * 16 + 8, fe_load(py));
+    }
+    const u32* sp = second ? s1 + (i - n0) * 8 : s0 + i * 8;
+    if (is_extra) sp = sel.extra_s[i - n01];
+    const bool is_inf = is_extra ? false : (second ? (inf1 && inf1[i - n0]) : (inf0 && inf0[i]));
+    Fe k = fe_from_mont<Fr>(fe_load(sp));
+    u32 flip = 0;
+    {
+      Fe nk = fe_neg<Fr>(k);
+      bool gt = false, decided = false;
+#pragma unroll
+      for (int t = 7; t >= 0; t--) {
+        if (!decided && k.v[t] != nk.v[t]) {
+          gt = k.v[t] > nk.v[t];
+          decided = true;
+        }
+      }
+      if (gt) {
+        k = nk;
+        flip = 0x80000000u;
+      }
+    }
+    // carry into window w: (k mod 2^(c*w)) > T_w
+    u32 carry = 0;
+    {
+      bool gt = false, decided = false;
+#pragma unroll
+      for (int t = 7; t >= 0; t--) {
+        u32 kv = k.v[t] & msk[t], tv = thr[t];
+        if (!decided && kv != tv) {
+          gt = kv > tv;
+          decided = true;
+        }
+      }
+      carry = gt ? 1u : 0u;
+    }
+    u32 raw = 0;
+    if (limb < 8) {
+      u32 lo = 0, hi = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        lo = (t == limb) ? k.v[t] : lo;
+        hi = (t == limb + 1) ? k.v[t] : hi;
+      }
+      unsigned long long two = ((unsigned long long)hi << 32) | lo;
+      raw = (u32)(two >> sh) & mask;
+    }
+    u32 v = raw + carry, key, val = (u32)i | (wid << wshift);
+    if (v > half) {
+      u32 mag = (1u << c) - v;
+      key = mag ? mag - 1 : invalid;
+      val = (val | 0x80000000u) ^ flip;
+    } else {
+      key = v ? v - 1 : invalid;
+      val ^= flip;
+    }
+    if (is_inf) key = invalid;
+    my_key[it] = key;
+    my_val[it] = val;
+    if (key != invalid) my_rank[it] = atomicAdd(&hist[key], 1u);
+  }
+  __syncthreads();
+  // bucket offsets inside this window's slice, and chunk offsets inside its chunk range:
+  // lane t owns buckets [t*per, (t+1)*per)
+  const u32 per = (n_buckets + kSmallThreads - 1) / kSmallThreads;
+  u32 cnt_sum = 0, chunk_sum = 0;
+  for (u32 q = 0; q < per; q++) {
+    u32 b = threadIdx.x * per + q;
+    if (b < n_buckets) {
+      cnt_sum += hist[b];
+      chunk_sum += (hist[b] + chunk - 1) / chunk;
+    }
+  }
+  u32 total_cnt, total_chunks;
+  u32 cnt_base = block_exclusive_scan(cnt_sum, wave_sums, &total_cnt);
+  u32 chunk_base = block_exclusive_scan(chunk_sum, wave_sums, &total_chunks);
+  for (u32 q = 0; q < per; q++) {
+    u32 b = threadIdx.x * per + q;
+    if (b < n_buckets) {
+      off[b] = cnt_base;
+      coff[b] = chunk_base;
+      cnt_base += hist[b];
+      chunk_base += (hist[b] + chunk - 1) / chunk;
+    }
+  }
+  __syncthreads();
+  const u32 slice = wid * (u32)n;  // this window's part of sorted_vals
+#pragma unroll
+  for (int it = 0; it < kSmallIters; it++)
+    if (my_key[it] != invalid) sorted_vals[slice + off[my_key[it]] + my_rank[it]] = my_val[it];
+  const u32 cbase = wid * cap_w;
+  for (u32 b = threadIdx.x; b < n_buckets; b += kSmallThreads) {
+    const u32 gb = wid * n_buckets + b, cnt = hist[b], st = slice + off[b];
+    const u32 nc = (cnt + chunk - 1) / chunk;
+    bucket_start[gb] = st;
+    bucket_end[gb] = st + cnt;
+    nch[gb] = nc;
+    choff[gb] = cbase + coff[b];
+    for (u32 q = 0; q < nc; q++) {
+      u32 t = cbase + coff[b] + q;
+      u32 len = cnt - q * chunk;
+      len = len > chunk ? chunk : len;
+      desc_b[t] = gb;
+      desc_s[t] = st + q * chunk;
+      ckey[t] = chunk < kChunkKeyInvalid ? chunk - len : (u32)((size_t)(chunk - len) * (kChunkKeyInvalid - 1) / chunk);
+      cval[t] = t;
+    }
+  }
+  for (u32 t = total_chunks + threadIdx.x; t < cap_w; t += kSmallThreads) {
+    ckey[cbase + t] = kChunkKeyInvalid;
+    cval[cbase + t] = cbase + t;
   }
 }
 
@@ -554,6 +782,9 @@ hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int
   return hipGetLastError();
 }
 
+static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st,
+                               hipEvent_t ev_acc0, hipEvent_t ev_acc1);
+
 hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExtra* extra, const MsmPlan& plan,
                    const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
   const size_t n = plan.n_total;
@@ -584,6 +815,17 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     if (p1.sel_half && p1.n % (2 * p1.sel_half)) return hipErrorInvalidValue;
     if (!p0.sel_half && !p1.sel_half && p0.n && p1.n && p0.group_lo > p1.group_lo) return hipErrorInvalidValue;
   }
+  if (plan.small) {
+    // sorted entries, bounds and the (unsorted) chunk table straight into the buffers the
+    // accumulation kernels read
+    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_small_front<C>, dim3((unsigned)plan.n_windows), dim3(kSmallThreads), 0, st,
+                                             p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x, p0.y, p1.x, p1.y, ws.packed,
+                                             sel, plan.c, plan.group_windows, plan.n_buckets, plan.wshift, plan.chunk,
+                                             plan.cap_w, ws.vals_b, ws.bucket_start, ws.bucket_end, ws.nch, ws.choff,
+                                             ws.ckey_b, ws.cval_b, ws.desc_b, ws.desc_s, ws.heavy_count));
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
+  }
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_digits<C>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                            st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, plan.c,
                                            plan.group_windows, plan.n_buckets, plan.wshift, ws.keys_a, ws.vals_a, p0.x, p0.y, p1.x, p1.y,
@@ -613,6 +855,14 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
   e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
       ws.csort_tmp, tmp, ws.ckey_a, ws.ckey_b, ws.cval_a, ws.cval_b, plan.nc_cap, 0, kChunkKeyBits, st, false);
   if (e != hipSuccess) return e;
+  return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
+}
+
+// accumulation and reduction over a finished entry order and chunk table
+static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st,
+                               hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
+  const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
+  hipError_t e;
   if (ev_acc0 && (e = hipEventRecord(ev_acc0, st)) != hipSuccess) return e;
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_chunk_sums<C>, dim3((unsigned)((plan.nc_cap + 127) / 128)), dim3(128),
                                            0, st, ws.packed, ws.vals_b, ws.ckey_b, ws.cval_b,
