@@ -74,6 +74,10 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   if (groups < 1 || groups > 2) return hipErrorInvalidValue;
   p.groups = groups;
   p.c = (c_override >= 2 && c_override <= 20) ? c_override : msm_choose_window(n_total / groups);
+  // below kSmallMaxPoints the one-launch front end and the tree kernels apply, and 8-bit
+  // windows (128 buckets, no short top window) are fastest from 2^9 points up
+  const bool small_ok = n_total > 0 && n_total <= kSmallMaxPoints && !getenv("BP_MSM_NO_SMALL");
+  if (small_ok && !(c_override >= 2 && c_override <= 20)) p.c = n_total / groups >= 512 ? 8 : 4;
   // k_digits maps a scalar k > r/2 to r - k (and negates the point), so digits
   // come from a value below 2^255 (secp256k1) or 2^254 (Vesta); one more bit
   // absorbs the carry of the signed recoding.
@@ -130,7 +134,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   // number of partial sums per bucket small
   if ((p.entries >> 21) > p.chunk) p.chunk = (u32)((p.entries >> 21) > 4096 ? 4096 : (p.entries >> 21));
   p.nc_cap = p.entries / p.chunk + nbt + 1;
-  p.small = n_total > 0 && n_total <= kSmallMaxPoints && p.n_buckets <= kSmallMaxBuckets && !getenv("BP_MSM_NO_SMALL");
+  p.small = small_ok && p.n_buckets <= kSmallMaxBuckets;
   if (p.small) {
     // every window owns a fixed range of the sorted-entry array and of the chunk table
     p.cap_w = (u32)(n_total / p.chunk + p.n_buckets + 1);
@@ -686,6 +690,188 @@ __global__ __launch_bounds__(256) void k_bucket_heavy(const u32* __restrict__ nc
   }
 }
 
+// ---- 4'. bucket accumulation for small problems ---------------------------------------
+// With few buckets there are lanes to spare, and what counts is the length of the
+// dependent chain: `lanes` (a power of two <= 64) lanes share a bucket, each adds every
+// lanes-th entry, and a shuffle tree joins them.  Buckets with more than `heavy_from`
+// entries (16 per lane) are queued for a whole block.
+
+BP_DEV Xyzz xyzz_shfl_down(const Xyzz& p, int delta, int width) {
+  Xyzz r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    r.x.v[i] = __shfl_down(p.x.v[i], delta, width);
+    r.y.v[i] = __shfl_down(p.y.v[i], delta, width);
+    r.zz.v[i] = __shfl_down(p.zz.v[i], delta, width);
+    r.zzz.v[i] = __shfl_down(p.zzz.v[i], delta, width);
+  }
+  return r;
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ packed, const u32* __restrict__ vals,
+                                                     const u32* __restrict__ start, const u32* __restrict__ end,
+                                                     size_t nbt, int lanes, u32 heavy_from, u32 idx_mask,
+                                                     u32* __restrict__ buckets, u32* __restrict__ heavy,
+                                                     u32* __restrict__ heavy_count) {
+  using F = typename C::Fq;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t b = t / (size_t)lanes;
+  const u32 sub = (u32)(t % (size_t)lanes);
+  const bool live = b < nbt;  // whole lane groups are live or not; all lanes take part in the shuffles
+  u32 s = 0, e = 0;
+  if (live) {
+    s = start[b];
+    e = end[b];
+  }
+  const bool is_heavy = e - s > heavy_from;
+  if (is_heavy) {
+    if (sub == 0) heavy[atomicAdd(heavy_count, 1u)] = (u32)b;
+    e = s;
+  }
+  Xyzz acc = xyzz_identity<F>();
+  for (u32 p = s + sub; p < e; p += (u32)lanes) {
+    u32 v = vals[p];
+    size_t idx = v & idx_mask;
+    Fe qx = fe_load(packed + idx * 16);
+    Fe qy = fe_load(packed + idx * 16 + 8);
+    if (v >> 31) qy = fe_neg<F>(qy);
+    xyzz_madd<F>(acc, qx, qy);
+  }
+  for (int off = lanes >> 1; off > 0; off >>= 1) {
+    Xyzz o = xyzz_shfl_down(acc, off, lanes);
+    if ((int)sub < off) xyzz_add<F>(acc, o);
+  }
+  if (live && !is_heavy && sub == 0) xyzz_store_soa(buckets, nbt, b, acc);
+}
+
+// one 1024-lane block per queued bucket: strided mixed additions, shuffle tree per wave,
+// then the 16 wave sums by the first wave
+template <class C>
+__global__ __launch_bounds__(1024) void k_bucket_heavy_entries(const u32* __restrict__ packed,
+                                                               const u32* __restrict__ vals,
+                                                               const u32* __restrict__ start,
+                                                               const u32* __restrict__ end, size_t nbt,
+                                                               u32 idx_mask, u32* __restrict__ buckets,
+                                                               const u32* __restrict__ heavy,
+                                                               const u32* __restrict__ heavy_count) {
+  using F = typename C::Fq;
+  __shared__ u32 lds[16 * 32];
+  const u32 count = *heavy_count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (u32 q = blockIdx.x; q < count; q += gridDim.x) {
+    const u32 b = heavy[q];
+    const u32 s = start[b], e = end[b];
+    Xyzz acc = xyzz_identity<F>();
+    for (u32 p = s + threadIdx.x; p < e; p += blockDim.x) {
+      u32 v = vals[p];
+      size_t idx = v & idx_mask;
+      Fe qx = fe_load(packed + idx * 16);
+      Fe qy = fe_load(packed + idx * 16 + 8);
+      if (v >> 31) qy = fe_neg<F>(qy);
+      xyzz_madd<F>(acc, qx, qy);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      Xyzz o = xyzz_shfl_down(acc, off, 64);
+      if (lane < off) xyzz_add<F>(acc, o);
+    }
+    if (lane == 0) xyzz_store_aos(lds + wave * 32, acc);
+    __syncthreads();
+    if (wave == 0) {
+      acc = lane < 16 ? xyzz_load_aos(lds + lane * 32) : xyzz_identity<F>();
+      for (int off = 8; off > 0; off >>= 1) {
+        Xyzz o = xyzz_shfl_down(acc, off, 64);
+        if (lane < off) xyzz_add<F>(acc, o);
+      }
+      if (lane == 0) xyzz_store_soa(buckets, nbt, b, acc);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- 5'. window value for 64..256 buckets in one block -------------------------------------
+// V = sum_{m=1}^{NB} m * B_{m-1}.  Slot m of an LDS array holds B_{m-1} (slot 0 the
+// identity; m = NB is kept aside).  A binary sum tree is built in place: after step t the
+// slots whose index is a multiple of 2^t hold the sums of 2^t consecutive slots.  The slots
+// with exactly b trailing zero bits are the odd blocks of level b, and their sum S_b is
+// the sum of all B whose weight m has bit b set; each S_b is reduced in place by a tree of
+// its own that starts as soon as level b exists, so all of them are complete after
+// log2(NB) - 1 steps of one addition each.  Then V = sum_b 2^b S_b + NB * B_{NB-1} by a
+// pairwise combination (1 + 2 + 4 + ... doublings on the longest path).
+template <class C>
+__global__ __launch_bounds__(256) void k_window_reduce_small(const u32* __restrict__ buckets, size_t nbt,
+                                                             u32 n_buckets, int log_nb,
+                                                             u32* __restrict__ windows) {
+  using F = typename C::Fq;
+  __shared__ u32 slot[256 * 32];
+  __shared__ u32 term[16 * 32];
+  const u32 w = blockIdx.x, tid = threadIdx.x, nb = n_buckets;
+  const size_t base = (size_t)w * nb;
+  if (tid < nb) {
+    Xyzz v = tid == 0 ? xyzz_identity<F>() : xyzz_load_soa(buckets, nbt, base + tid - 1);
+    xyzz_store_aos(slot + tid * 32, v);
+  }
+  __syncthreads();
+  for (int t = 1; t <= log_nb - 1; t++) {
+    // tasks of this step: the sum-tree level (nb >> t additions), then for every level
+    // b < t one step of the S_b tree (nb >> (t+1) additions each)
+    const u32 chain = nb >> t, per = nb >> (t + 1);
+    u32 dst = 0, src = 0;
+    bool work = false;
+    if (tid < chain) {
+      dst = tid << t;
+      src = dst + (1u << (t - 1));
+      work = true;
+    } else {
+      u32 q = tid - chain;
+      u32 b = q / per, j = q % per;
+      if (b < (u32)t) {
+        const int r = t - (int)b;          // step number inside the S_b tree
+        u32 k = j << r;                    // k = 0 mod 2^r
+        dst = (2 * k + 1) << b;
+        src = (2 * (k + (1u << (r - 1))) + 1) << b;
+        work = true;
+      }
+    }
+    Xyzz a, o;
+    if (work) {
+      a = xyzz_load_aos(slot + dst * 32);
+      o = xyzz_load_aos(slot + src * 32);
+    }
+    __syncthreads();
+    if (work) {
+      xyzz_add<F>(a, o);
+      xyzz_store_aos(slot + dst * 32, a);
+    }
+    __syncthreads();
+  }
+  // terms: T_b = S_b = slot[2^b] for b < log_nb, T_{log_nb} = B_{NB-1}
+  const int n_terms = log_nb + 1;
+  if ((int)tid < n_terms) {
+    Xyzz v = (int)tid < log_nb ? xyzz_load_aos(slot + ((size_t)1 << tid) * 32)
+                               : xyzz_load_soa(buckets, nbt, base + nb - 1);
+    xyzz_store_aos(term + tid * 32, v);
+  }
+  __syncthreads();
+  for (int sft = 1; sft < n_terms; sft <<= 1) {
+    const bool work = (int)tid < n_terms && (tid % (2 * sft)) == 0 && (int)tid + sft < n_terms;
+    Xyzz a, o;
+    if (work) {
+      a = xyzz_load_aos(term + tid * 32);
+      o = xyzz_load_aos(term + (tid + sft) * 32);
+      for (int d = 0; d < sft; d++) o = xyzz_dbl<F>(o);
+      xyzz_add<F>(a, o);
+    }
+    __syncthreads();
+    if (work) xyzz_store_aos(term + tid * 32, a);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    Xyzz v = xyzz_load_aos(term);
+    xyzz_store_aos(windows + (size_t)w * 32, v);
+  }
+}
+
 // ---- 5. bucket reduction ----------------------------------------------------------
 // Window value = sum_{j=0}^{NB-1} (j+1)*B_j.  A thread takes seg_len consecutive
 // buckets: T = sum (j-j0+1)*B_j by a running sum, S = sum B_j, and emits
@@ -863,20 +1049,45 @@ static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspac
                                hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
   const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
   hipError_t e;
+  const u32 idx_mask = (1u << plan.wshift) - 1u;
   if (ev_acc0 && (e = hipEventRecord(ev_acc0, st)) != hipSuccess) return e;
-  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_chunk_sums<C>, dim3((unsigned)((plan.nc_cap + 127) / 128)), dim3(128),
-                                           0, st, ws.packed, ws.vals_b, ws.ckey_b, ws.cval_b,
-                                           ws.desc_b, ws.desc_s, ws.bucket_end, ws.nch, nbt, plan.chunk, plan.nc_cap, (1u << plan.wshift) - 1u, ws.buckets,
-                                           ws.chunk_sums));
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;
-  DISPATCH_CURVE(curve, {
-    hipLaunchKernelGGL(k_bucket_finish<C>, dim3((unsigned)((nbt + 127) / 128)), dim3(128), 0, st, ws.nch, ws.choff,
-                       nbt, plan.nc_cap, ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
-    hipLaunchKernelGGL(k_bucket_heavy<C>, dim3(256), dim3(256), 0, st, ws.nch, ws.choff, nbt, plan.nc_cap,
-                       ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
-  });
-  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (plan.small) {
+    // lanes per bucket: as many as keep the launch at about one wave per SIMD
+    int lanes = 64;
+    while (lanes > 1 && nbt * (size_t)lanes > 65536) lanes >>= 1;
+    const size_t tree_threads = nbt * (size_t)lanes;
+    DISPATCH_CURVE(curve, {
+      hipLaunchKernelGGL(k_bucket_tree<C>, dim3((unsigned)((tree_threads + 255) / 256)), dim3(256), 0, st, ws.packed,
+                         ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, lanes, (u32)(16 * lanes), idx_mask, ws.buckets,
+                         ws.heavy, ws.heavy_count);
+      hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3(256), dim3(1024), 0, st, ws.packed, ws.vals_b,
+                         ws.bucket_start, ws.bucket_end, nbt, idx_mask, ws.buckets, ws.heavy, ws.heavy_count);
+    });
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;
+  } else {
+    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_chunk_sums<C>, dim3((unsigned)((plan.nc_cap + 127) / 128)), dim3(128),
+                                             0, st, ws.packed, ws.vals_b, ws.ckey_b, ws.cval_b, ws.desc_b, ws.desc_s,
+                                             ws.bucket_end, ws.nch, nbt, plan.chunk, plan.nc_cap, idx_mask, ws.buckets,
+                                             ws.chunk_sums));
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;
+    DISPATCH_CURVE(curve, {
+      hipLaunchKernelGGL(k_bucket_finish<C>, dim3((unsigned)((nbt + 127) / 128)), dim3(128), 0, st, ws.nch, ws.choff,
+                         nbt, plan.nc_cap, ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
+      hipLaunchKernelGGL(k_bucket_heavy<C>, dim3(256), dim3(256), 0, st, ws.nch, ws.choff, nbt, plan.nc_cap,
+                         ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
+    });
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  if (plan.small && plan.n_buckets >= 64 && plan.n_buckets <= 256) {
+    int log_nb = 0;
+    while ((1u << log_nb) < plan.n_buckets) log_nb++;
+    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_window_reduce_small<C>, dim3((unsigned)plan.n_windows),
+                                             dim3(plan.n_buckets), 0, st, ws.buckets, nbt, plan.n_buckets, log_nb,
+                                             ws.windows));
+    return hipGetLastError();
+  }
   size_t nseg_threads = (size_t)plan.n_windows * plan.n_segs;
   DISPATCH_CURVE(curve, {
     // 256-lane blocks: one wave on each SIMD of a CU.  The kernel is a long dependent chain
