@@ -104,8 +104,7 @@ struct MsmPlan {
   size_t nc_cap;  // upper bound on the number of chunks
   int seg_len;    // buckets per reduction segment
   u32 n_segs;     // per window
-  bool small;     // one-launch front end (digits, counting sort, bounds, chunk table) per window
-  u32 cap_w;      // small: chunk-table slots per window
+  bool small;     // one-launch front end (digits, counting sort, bounds) per window, tree accumulation
 };
 
 int msm_choose_window(size_t n);

@@ -1,11 +1,18 @@
 // Multi-scalar multiplication for gfx950: Pippenger's bucket method with signed
 // c-bit digits.
-//   1. k_digits      scalars: Montgomery -> integer -> W signed digits; emits one
-//                    (bucket key, point index | sign) pair per point and window
-//   2. radix sort    pairs by bucket key (rocPRIM device radix sort)
-//   3. k_bounds      first/last sorted position of every bucket
-//   4. k_accumulate  bucket sums in XYZZ coordinates with mixed additions
-//   5. k_reduce_*    sum_b b*B_b per window by segmented running sums
+//   1. k_digits      scalars: Montgomery -> integer (folded to |k| <= r/2) -> W signed
+//                    digits; emits one (bucket, sign | window | point index) pair per point
+//                    and window, and packs x|y of every point into one 64-byte record
+//   2. radix sort    pairs by bucket (rocPRIM; stable, input window-major)
+//   3. k_bounds      first/last sorted position of every (window, bucket)
+//   4. k_chunk_*     buckets cut into chunks of bounded length, chunk ids sorted by length,
+//                    one lane per chunk sums it in XYZZ coordinates with mixed additions;
+//                    k_bucket_finish / k_bucket_heavy join the chunks of a bucket
+//   5. k_reduce_segments, k_group_sum   sum_b b*B_b per window by segmented running sums
+// Up to kSmallMaxPoints points the launch count dominates, and steps 1-3 are one kernel
+// (k_small_front), step 4 a lane-group tree per bucket (k_bucket_tree) and step 5 one block
+// per window (k_window_reduce_small).  A plan can carry two output groups (two independent
+// sums from one pass) and one extra device-side (point, scalar) per group.
 // The W window sums go back to the host, which finishes sum_w 2^(c*w) W_w (a
 // strictly sequential chain of ~256 doublings, slower on a GPU lane than on a CPU
 // core).  Stands in for ark-ec 0.5.0 VariableBaseMSM::msm_unchecked as called at
@@ -136,9 +143,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   p.nc_cap = p.entries / p.chunk + nbt + 1;
   p.small = small_ok && p.n_buckets <= kSmallMaxBuckets;
   if (p.small) {
-    // every window owns a fixed range of the sorted-entry array and of the chunk table
-    p.cap_w = (u32)(n_total / p.chunk + p.n_buckets + 1);
-    p.nc_cap = (size_t)p.n_windows * p.cap_w;
+    // every window owns a fixed range of n_total slots of the sorted-entry array
     size_t need = (size_t)p.n_windows * n_total * sizeof(u32);
     if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
   }
@@ -283,10 +288,10 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
 
 // ---- 1-3 for small problems ---------------------------------------------------------
 // Up to kSmallMaxPoints points: one 1024-lane block per (group, window) does what k_digits,
-// the radix sort, k_bounds, the chunk count/scan and k_chunk_desc do for large inputs --
-// digits of its window, a counting sort in LDS (bucket histogram with LDS atomics whose
-// return value is the entry's rank inside its bucket, block scan, scatter), bucket bounds
-// and the chunk table of its window -- in one launch instead of about forty.  A small MSM
+// the radix sort and k_bounds do for large inputs -- digits of its window, a counting sort
+// in LDS (bucket histogram with LDS atomics whose return value is the entry's rank inside
+// its bucket, block scan, scatter) and the bucket bounds -- in one launch instead of about
+// thirty; the accumulation (k_bucket_tree) needs no chunk table.  A small MSM
 // is a chain of dependent launches, so the launch count is what it costs.  The order of
 // entries inside a bucket is arbitrary here; the bucket's sum does not depend on it.
 
@@ -322,14 +327,11 @@ __global__ __launch_bounds__(1024) void k_small_front(
     const u32* __restrict__ s0, const uint8_t* __restrict__ inf0, size_t n0, const u32* __restrict__ s1,
     const uint8_t* __restrict__ inf1, size_t n1, const u32* __restrict__ x0, const u32* __restrict__ y0,
     const u32* __restrict__ x1, const u32* __restrict__ y1, u32* __restrict__ packed, DigitGroups sel, int c,
-    int group_windows, u32 n_buckets, int wshift, u32 chunk, u32 cap_w, u32* __restrict__ sorted_vals,
-    u32* __restrict__ bucket_start, u32* __restrict__ bucket_end, u32* __restrict__ nch, u32* __restrict__ choff,
-    u32* __restrict__ ckey, u32* __restrict__ cval, u32* __restrict__ desc_b, u32* __restrict__ desc_s,
-    u32* __restrict__ heavy_count) {
+    int group_windows, u32 n_buckets, int wshift, u32* __restrict__ sorted_vals, u32* __restrict__ bucket_start,
+    u32* __restrict__ bucket_end, u32* __restrict__ heavy_count) {
   using Fr = typename C::Fr;
   __shared__ u32 hist[kSmallMaxBuckets];
   __shared__ u32 off[kSmallMaxBuckets];
-  __shared__ u32 coff[kSmallMaxBuckets];
   __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
   __shared__ u32 thr[8], msk[8];  // window w: carry-in threshold T_w and the mask of the low c*w bits
   const u32 wid = blockIdx.x;
@@ -445,27 +447,20 @@ __global__ __launch_bounds__(1024) void k_small_front(
     if (key != invalid) my_rank[it] = atomicAdd(&hist[key], 1u);
   }
   __syncthreads();
-  // bucket offsets inside this window's slice, and chunk offsets inside its chunk range:
-  // lane t owns buckets [t*per, (t+1)*per)
+  // bucket offsets inside this window's slice: lane t owns buckets [t*per, (t+1)*per)
   const u32 per = (n_buckets + kSmallThreads - 1) / kSmallThreads;
-  u32 cnt_sum = 0, chunk_sum = 0;
+  u32 cnt_sum = 0;
   for (u32 q = 0; q < per; q++) {
     u32 b = threadIdx.x * per + q;
-    if (b < n_buckets) {
-      cnt_sum += hist[b];
-      chunk_sum += (hist[b] + chunk - 1) / chunk;
-    }
+    if (b < n_buckets) cnt_sum += hist[b];
   }
-  u32 total_cnt, total_chunks;
+  u32 total_cnt;
   u32 cnt_base = block_exclusive_scan(cnt_sum, wave_sums, &total_cnt);
-  u32 chunk_base = block_exclusive_scan(chunk_sum, wave_sums, &total_chunks);
   for (u32 q = 0; q < per; q++) {
     u32 b = threadIdx.x * per + q;
     if (b < n_buckets) {
       off[b] = cnt_base;
-      coff[b] = chunk_base;
       cnt_base += hist[b];
-      chunk_base += (hist[b] + chunk - 1) / chunk;
     }
   }
   __syncthreads();
@@ -473,27 +468,10 @@ __global__ __launch_bounds__(1024) void k_small_front(
 #pragma unroll
   for (int it = 0; it < kSmallIters; it++)
     if (my_key[it] != invalid) sorted_vals[slice + off[my_key[it]] + my_rank[it]] = my_val[it];
-  const u32 cbase = wid * cap_w;
   for (u32 b = threadIdx.x; b < n_buckets; b += kSmallThreads) {
-    const u32 gb = wid * n_buckets + b, cnt = hist[b], st = slice + off[b];
-    const u32 nc = (cnt + chunk - 1) / chunk;
+    const u32 gb = wid * n_buckets + b, st = slice + off[b];
     bucket_start[gb] = st;
-    bucket_end[gb] = st + cnt;
-    nch[gb] = nc;
-    choff[gb] = cbase + coff[b];
-    for (u32 q = 0; q < nc; q++) {
-      u32 t = cbase + coff[b] + q;
-      u32 len = cnt - q * chunk;
-      len = len > chunk ? chunk : len;
-      desc_b[t] = gb;
-      desc_s[t] = st + q * chunk;
-      ckey[t] = chunk < kChunkKeyInvalid ? chunk - len : (u32)((size_t)(chunk - len) * (kChunkKeyInvalid - 1) / chunk);
-      cval[t] = t;
-    }
-  }
-  for (u32 t = total_chunks + threadIdx.x; t < cap_w; t += kSmallThreads) {
-    ckey[cbase + t] = kChunkKeyInvalid;
-    cval[cbase + t] = cbase + t;
+    bucket_end[gb] = st + hist[b];
   }
 }
 
@@ -1002,13 +980,11 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     if (!p0.sel_half && !p1.sel_half && p0.n && p1.n && p0.group_lo > p1.group_lo) return hipErrorInvalidValue;
   }
   if (plan.small) {
-    // sorted entries, bounds and the (unsorted) chunk table straight into the buffers the
-    // accumulation kernels read
+    // sorted entries and bucket bounds straight into the buffers the accumulation reads
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_small_front<C>, dim3((unsigned)plan.n_windows), dim3(kSmallThreads), 0, st,
                                              p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x, p0.y, p1.x, p1.y, ws.packed,
-                                             sel, plan.c, plan.group_windows, plan.n_buckets, plan.wshift, plan.chunk,
-                                             plan.cap_w, ws.vals_b, ws.bucket_start, ws.bucket_end, ws.nch, ws.choff,
-                                             ws.ckey_b, ws.cval_b, ws.desc_b, ws.desc_s, ws.heavy_count));
+                                             sel, plan.c, plan.group_windows, plan.n_buckets, plan.wshift, ws.vals_b,
+                                             ws.bucket_start, ws.bucket_end, ws.heavy_count));
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
   }
