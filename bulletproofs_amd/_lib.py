@@ -91,6 +91,7 @@ SIGNATURES = {
     "bp_ipa_round_lr": (ci, [vp, vp, vp, vp, vp]),
     "bp_ipa_round_fold": (ci, [vp, vp, vp]),
     "bp_ipa_len": (sz, [vp]),
+    "bp_msm_resident_s_vector": (ci, [vp, vp, sz, vp, vp, sz, vp]),
     "bp_ipa_begin_resident": (ci, [vp, vp, ci, sz, sz, vp, vp, sz, C.POINTER(vp)]),
     "bp_ipa_scale_h": (ci, [vp, vp]),
     "bp_ipa_set_u": (ci, [vp, vp]),

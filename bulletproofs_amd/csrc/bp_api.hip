@@ -585,6 +585,23 @@ int bp_s_vector(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_i
   return BP_OK;
 }
 
+int bp_msm_resident_s_vector(bp_ctx* ctx, const bp_bases* bases, size_t offset, const uint64_t* ch,
+                             const uint64_t* ch_inv, size_t k, uint64_t out_xyz[12]) {
+  if (!ctx || !bases || !out_xyz || (k && (!ch || !ch_inv))) return fail(ctx, BP_E_ARG, "bp_msm_resident_s_vector: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_msm_resident_s_vector: bases belong to another context");
+  if (k > 28) return fail(ctx, BP_E_ARG, "bp_msm_resident_s_vector: k > 28");
+  const size_t n = (size_t)1 << k;
+  if (offset > bases->n || n > bases->n - offset) return fail(ctx, BP_E_ARG, "bp_msm_resident_s_vector: range outside bases");
+  Guard g(ctx);
+  // the 2^k scalars never leave the device
+  void* ds;
+  CHK(reserve(ctx, S_IN3, n * 32, &ds));
+  CHK(s_vector_common(ctx, bases->curve, ch, ch_inv, k, (u32*)ds));
+  MsmPart p0{bases->x + offset * 8, bases->y + offset * 8, bases->inf + offset, (const u32*)ds, n};
+  MsmPart p1{nullptr, nullptr, nullptr, nullptr, 0};
+  return msm_full(ctx, bases->curve, p0, p1, out_xyz);
+}
+
 int bp_powers(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* out) {
   if (!ctx || !x || (n && !out)) return fail(ctx, BP_E_ARG, "bp_powers: null argument");
   if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");

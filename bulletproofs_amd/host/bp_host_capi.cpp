@@ -375,3 +375,115 @@ int bph_range_agg_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const ui
 }
 
 }  // extern "C"
+
+// ---- polynomial commitment round trip -----------------------------------------------------
+#include "bp_host_poly.hpp"
+
+namespace {
+
+template <class Fq, class Fr, int CURVE>
+int poly_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uint64_t* h_gen_xy, const uint64_t* coeffs,
+                   size_t n_coeffs, size_t n, const uint64_t* r_x, uint64_t seed_rand, uint64_t seed_chal, int tamper,
+                   int halo, uint64_t* out_l, uint64_t* out_r, uint64_t* out_ar, uint64_t* out_g, uint64_t* out_commit,
+                   uint64_t* out_eval, double* prove_ms, double* verify_ms, int* ok_verify, int* ok_lazy, int* ok_halo) {
+  using PC = PolyCommit<Fq, Fr, CURVE>;
+  using S = ScalarOps<Fr>;
+  typename PC::Crs crs;
+  crs.gs = unpack(gx, gy, nullptr, n);
+  auto pt = [&](int k) { Affine a; memcpy(a.x, h_gen_xy + 8 * k, 32); memcpy(a.y, h_gen_xy + 8 * k + 4, 32); a.inf = 0; return a; };
+  crs.h = pt(0); crs.gen = pt(1);
+  PC::register_bases(ctx, crs);
+  *ok_verify = *ok_lazy = *ok_halo = 0;
+  try {
+    std::vector<Scalar> p = unpack_s(coeffs, n_coeffs);
+    Scalar r, x;
+    memcpy(r.l, r_x, 32); memcpy(x.l, r_x + 4, 32);
+    auto st = PC::statement(ctx, crs, p, r, x);
+    PolyProof proof;
+    SeededTranscript<Fr> t1(seed_chal);
+    SeededRandom<Fr> rng(seed_rand);
+    auto a0 = std::chrono::steady_clock::now();
+    Todo todo = PC::prove(ctx, crs, st, p, r, t1, rng, proof);
+    auto a1 = std::chrono::steady_clock::now();
+    auto st_check = st;
+    if (tamper) st_check.evaluation = S::add(st_check.evaluation, S::one());
+    SeededTranscript<Fr> t2(seed_chal);
+    auto b0 = std::chrono::steady_clock::now();
+    *ok_verify = PC::verify(ctx, crs, st_check, proof, t2) ? 1 : 0;
+    auto b1 = std::chrono::steady_clock::now();
+    *prove_ms = std::chrono::duration<double, std::milli>(a1 - a0).count();
+    *verify_ms = std::chrono::duration<double, std::milli>(b1 - b0).count();
+    std::vector<Todo> todos;
+    SeededTranscript<Fr> t3(seed_chal);
+    *ok_lazy = PC::lazy_verify(ctx, crs, st_check, todo.g, proof, t3, todos) ? 1 : 0;
+    size_t k = proof.L.size();
+    for (size_t j = 0; j < k; j++) { memcpy(out_l + 12 * j, proof.L[j].xyz, 96); memcpy(out_r + 12 * j, proof.R[j].xyz, 96); }
+    memcpy(out_ar, proof.a.l, 32); memcpy(out_ar + 4, proof.r.l, 32);
+    memcpy(out_g, todo.g.x, 32); memcpy(out_g + 4, todo.g.y, 32); out_g[8] = todo.g.inf;
+    memcpy(out_commit, st.commitment.xyz, 96);
+    memcpy(out_eval, st.evaluation.l, 32);
+    if (halo && !tamper) {
+      // a second opening (reversed coefficients), both checked lazily; then the two deferred
+      // MSMs are folded into one statement that is proved and fully verified (the
+      // "halo trick": src/poly_commit/mod.rs:228-262, benches/poly_commit_bench.rs)
+      std::vector<Scalar> p2(p.rbegin(), p.rend());
+      auto st2 = PC::statement(ctx, crs, p2, r, x);
+      PolyProof proof2;
+      SeededTranscript<Fr> t4(seed_chal + 7777);
+      SeededRandom<Fr> rng2(seed_rand + 7777);
+      Todo todo2 = PC::prove(ctx, crs, st2, p2, r, t4, rng2, proof2);
+      SeededTranscript<Fr> t5(seed_chal + 7777);
+      bool ok = PC::lazy_verify(ctx, crs, st2, todo2.g, proof2, t5, todos) && todos.size() == 2;
+      SeededTranscript<Fr> tc(seed_chal ^ 0xA1FAull);
+      Scalar alpha = tc.verifier_scalar(), x2 = tc.verifier_scalar();
+      std::vector<Scalar> w = PC::fold_todos_witness(ctx, todos, alpha);
+      auto fst = PC::fold_todos_statement(ctx, todos, alpha, x2);
+      auto wst = PC::statement(ctx, crs, w, S::zero(), x2);
+      ok = ok && memcmp(wst.commitment.xyz, fst.commitment.xyz, 96) == 0 && wst.evaluation == fst.evaluation;
+      PolyProof proof3;
+      SeededTranscript<Fr> t6(seed_chal + 9999);
+      SeededRandom<Fr> rng3(seed_rand + 9999);
+      PC::prove(ctx, crs, fst, w, S::zero(), t6, rng3, proof3);
+      SeededTranscript<Fr> t7(seed_chal + 9999);
+      ok = ok && PC::verify(ctx, crs, fst, proof3, t7);
+      *ok_halo = ok ? 1 : 0;
+    }
+  } catch (...) {
+    bp_bases_free(crs.bases);
+    throw;
+  }
+  bp_bases_free(crs.bases);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Opening proof of a polynomial of n_coeffs coefficients under a CRS of n = 2^k generators:
+// statement, prove, verify, lazy_verify, and (halo != 0) the fold of two deferred checks.
+// h_gen_xy = affine h, group generator (2 x 8 u64); r_x = blinder r, evaluation point x.
+// Outputs: L, R (k x 12 u64 each), (a, r), folded generator g (x|y|inf: 9 u64), the
+// commitment (12) and the evaluation (4) of the first statement.
+int bph_poly_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_t* gy, const uint64_t* h_gen_xy,
+                       const uint64_t* coeffs, size_t n_coeffs, size_t n, const uint64_t* r_x, uint64_t seed_rand,
+                       uint64_t seed_chal, int tamper, int halo, uint64_t* out_l, uint64_t* out_r, uint64_t* out_ar,
+                       uint64_t* out_g, uint64_t* out_commit, uint64_t* out_eval, double* prove_ms, double* verify_ms,
+                       int* ok_verify, int* ok_lazy, int* ok_halo) {
+  try {
+    if (curve == BP_SECP256K1)
+      return poly_roundtrip<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(ctx, gx, gy, h_gen_xy, coeffs, n_coeffs, n, r_x, seed_rand,
+                                                                   seed_chal, tamper, halo, out_l, out_r, out_ar, out_g,
+                                                                   out_commit, out_eval, prove_ms, verify_ms, ok_verify,
+                                                                   ok_lazy, ok_halo);
+    if (curve == BP_VESTA)
+      return poly_roundtrip<VestaFq, VestaFr, BP_VESTA>(ctx, gx, gy, h_gen_xy, coeffs, n_coeffs, n, r_x, seed_rand, seed_chal,
+                                                       tamper, halo, out_l, out_r, out_ar, out_g, out_commit, out_eval,
+                                                       prove_ms, verify_ms, ok_verify, ok_lazy, ok_halo);
+    return BP_E_CURVE;
+  } catch (const std::exception&) {
+    return BP_E_HIP;
+  }
+}
+
+}  // extern "C"

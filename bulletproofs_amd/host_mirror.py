@@ -113,3 +113,36 @@ def range_aggregate_throughput(device, curve, gs, hs, ugh_xy, values, gamma, n_b
     total = workers * reps
     return dict(ok=bool(ok.value), prove_wall_ms=tp.value, verify_wall_ms=tv.value,
                 prove_per_s=total / tp.value * 1e3, verify_per_s=total / tv.value * 1e3)
+
+
+hlib.bph_poly_roundtrip.restype = ci
+hlib.bph_poly_roundtrip.argtypes = [vp, ci, vp, vp, vp, vp, sz, sz, vp, C.c_uint64, C.c_uint64, ci, ci, vp, vp, vp, vp, vp, vp,
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+
+
+def poly_commit_roundtrip(ctx: Context, curve, gs, h_gen_xy, coeffs, r, x, seed_rand=1, seed_chal=2, tamper=False, halo=True):
+    """polynomial commitment opening (src/poly_commit): statement, prove, verify, lazy_verify and
+    the fold of two deferred checks, through the GPU path.  h_gen_xy: (2, 8) uint64 = affine h and
+    the group generator.  coeffs: up to n = len(gs) scalars; r, x: one scalar each."""
+    gx, gy, _ = _pts(gs)
+    n = gx.shape[0]
+    assert n & (n - 1) == 0
+    k = n.bit_length() - 1
+    coeffs = _f(coeffs)
+    rx = np.concatenate([_f(r).reshape(4), _f(x).reshape(4)])
+    h_gen_xy = np.ascontiguousarray(h_gen_xy, dtype=np.uint64).reshape(16)
+    L = np.zeros((max(k, 1), 12), dtype=np.uint64)
+    R = np.zeros((max(k, 1), 12), dtype=np.uint64)
+    ar = np.zeros((2, 4), dtype=np.uint64)
+    g = np.zeros(9, dtype=np.uint64)
+    com = np.zeros(12, dtype=np.uint64)
+    ev = np.zeros(4, dtype=np.uint64)
+    tp, tv = C.c_double(), C.c_double()
+    okv, okl, okh = ci(), ci(), ci()
+    rc = hlib.bph_poly_roundtrip(ctx.h, curve, _p(gx), _p(gy), _p(h_gen_xy), _p(coeffs), coeffs.shape[0], n, _p(rx), seed_rand,
+                                 seed_chal, int(tamper), int(halo), _p(L), _p(R), _p(ar), _p(g), _p(com), _p(ev),
+                                 C.byref(tp), C.byref(tv), C.byref(okv), C.byref(okl), C.byref(okh))
+    if rc:
+        raise RuntimeError(f"bph_poly_roundtrip rc={rc}")
+    return dict(L=L[:k], R=R[:k], a=ar[0], r=ar[1], g=g, commitment=com, evaluation=ev, prove_ms=tp.value,
+                verify_ms=tv.value, verify_ok=bool(okv.value), lazy_ok=bool(okl.value), halo_ok=bool(okh.value))

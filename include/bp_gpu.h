@@ -104,6 +104,11 @@ size_t bp_bases_len(const bp_bases* b);
  * src/ipa/types.rs:81-82). */
 int bp_msm_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
                     const uint64_t* scalars, uint64_t out_xyz[12]);
+/* MSM over bases[offset .. offset+2^k) with the s-vector of k challenges as scalars,
+ * built on the device and never copied: `G::msm_unchecked(&crs.gs, &h_poly.coeffs())`
+ * (src/poly_commit/mod.rs:109-111,152-159).  ch_inv[j] = ch[j]^-1; k <= 28. */
+int bp_msm_resident_s_vector(bp_ctx* ctx, const bp_bases* bases, size_t offset, const uint64_t* ch,
+                             const uint64_t* ch_inv, size_t k, uint64_t out_xyz[12]);
 
 /* Per-window partial sums of an MSM, left on the device for a multi-GPU combine:
  * writes *n_windows and *window_bits, and n_windows XYZZ points (4*4 u64 each)

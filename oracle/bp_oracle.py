@@ -625,3 +625,100 @@ def range_aggregate_prove(c: Curve, gs, hs, u, g, h, values, gammas, n_bits, ran
     Ls = [add(rd["L"], scalar_mul(rd["cL"], u2, c), c) for rd in rounds]   # src/ipa/mod.rs:43
     Rs = [add(rd["R"], scalar_mul(rd["cR"], u2, c), c) for rd in rounds]
     return dict(A=A, S=S, TT1=TT1, TT2=TT2, tao_x=tao_x, mu=mu, t_hat=t_hat, L=Ls, R=Rs, a=af[0], b=bf[0])
+
+
+# ---- polynomial commitment (src/poly_commit) ---------------------------------------------
+
+def poly_commit_statement(c: Curve, gs, h, coeffs, r, x):
+    """Witness::statement, src/poly_commit/types.rs:137-151: (commitment, evaluation)."""
+    mod = c.n
+    padded = list(coeffs) + [0] * (len(gs) - len(coeffs))
+    msm = msm_pippenger if len(gs) > 16 else msm_naive
+    commitment = add(msm(gs, padded, c), scalar_mul(r, h, c), c)
+    evaluation = inner_product(padded, powers(x, len(gs), mod), mod)
+    return commitment, evaluation
+
+
+def poly_commit_prove(c: Curve, gs, h, coeffs, r, x, rand_seed, chal_seed):
+    """poly_commit::prove, src/poly_commit/mod.rs:45-119.  Randomness: (l_j, r_j) per round
+    from one SplitMix64 stream; challenge number j is SplitMix64(chal_seed + j).field:
+    u_coeff first, then one u_j per round.  Returns (L list, R list, a, r, g_final, ui)."""
+    mod = c.n
+    n = len(gs)
+    rnd = SplitMix64(rand_seed)
+    counter = [0]
+
+    def chal():
+        v = SplitMix64(chal_seed + counter[0]).field(mod)
+        counter[0] += 1
+        return v
+
+    u = scalar_mul(chal(), c.g, c)                                         # :55-58
+    g = list(gs)
+    a = list(coeffs) + [0] * (n - len(coeffs))
+    b = powers(x, n, mod)                                                  # :65
+    msm = msm_pippenger if n > 32 else msm_naive
+    Ls, Rs, ui = [], [], []
+    while n != 1:
+        n //= 2
+        g_lo, g_hi, a_lo, a_hi, b_lo, b_hi = g[:n], g[n:], a[:n], a[n:], b[:n], b[n:]
+        l_j, r_j = rnd.field(mod), rnd.field(mod)                          # :75
+        left = add(add(msm(g_hi, a_lo, c), scalar_mul(l_j, h, c), c),
+                   scalar_mul(inner_product(a_lo, b_hi, mod), u, c), c)    # :78-80
+        right = add(add(msm(g_lo, a_hi, c), scalar_mul(r_j, h, c), c),
+                    scalar_mul(inner_product(a_hi, b_lo, mod), u, c), c)   # :83-85
+        Ls.append(left)
+        Rs.append(right)
+        u_j = chal()                                                       # :91
+        ui.append(u_j)
+        u_inv = pow(u_j, -1, mod)
+        a = fold_scalars(a_hi, a_lo, u_inv, u_j, mod)                      # :96
+        b = fold_scalars(b_lo, b_hi, u_inv, u_j, mod)                      # :97
+        g = fold_generators(g_lo, g_hi, u_inv, u_j, c)                     # :102
+        r = (r + l_j * u_j * u_j + r_j * u_inv * u_inv) % mod              # :104
+    return Ls, Rs, a[0], r, g[0], ui
+
+
+def poly_commit_check(c: Curve, gs, h, commitment, evaluation, x, Ls, Rs, a, r, chal_seed, g_assumed=None):
+    """poly_commit::verify (src/poly_commit/mod.rs:121-173), or lazy_verify (:264-315) when
+    g_assumed is given: returns (accepted, ui)."""
+    mod = c.n
+    counter = [0]
+
+    def chal():
+        v = SplitMix64(chal_seed + counter[0]).field(mod)
+        counter[0] += 1
+        return v
+
+    u = scalar_mul(chal(), c.g, c)
+    q = add(commitment, scalar_mul(evaluation, u, c), c)                   # :137
+    ui = []
+    for L, R in zip(Ls, Rs):
+        u_j = chal()
+        ui.append(u_j)
+        u_inv = pow(u_j, -1, mod)
+        q = add(add(q, scalar_mul(u_j * u_j % mod, L, c), c), scalar_mul(u_inv * u_inv % mod, R, c), c)  # :147-150
+    if g_assumed is None:
+        ss = s_vector(ui, mod)                                             # :152-157
+        msm = msm_pippenger if len(gs) > 32 else msm_naive
+        g = msm(gs, ss, c)                                                 # :159
+        b = inner_product(ss, powers(x, len(gs), mod), mod)                # :160-163
+    else:
+        g = g_assumed
+        b = hpoly_evaluate(ui, x, mod)                                     # :301
+    res = add(add(scalar_mul(a, g, c), scalar_mul(r, h, c), c), scalar_mul(a * b % mod, u, c), c)
+    return res == q, ui                                                    # :166-172
+
+
+def fold_todos(c: Curve, todos, alpha, x):
+    """fold_todos_witness / fold_todos_statement (src/poly_commit/mod.rs:228-262).
+    todos: list of (g point, ui).  Returns (coeffs, commitment, evaluation)."""
+    mod = c.n
+    coeffs, commitment, evaluation, ai = None, None, 0, 1
+    for g, ui in todos:
+        ss = s_vector(ui, mod)
+        coeffs = [ai * v % mod for v in ss] if coeffs is None else [(u + ai * v) % mod for u, v in zip(coeffs, ss)]
+        commitment = add(commitment, scalar_mul(ai, g, c), c)
+        evaluation = (evaluation + ai * hpoly_evaluate(ui, x, mod)) % mod
+        ai = ai * alpha % mod
+    return coeffs, commitment, evaluation

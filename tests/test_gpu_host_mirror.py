@@ -99,3 +99,37 @@ def test_aggregated_range_proof(ctx, c, m, n_bits):
     bad = host_mirror.range_aggregate_roundtrip(ctx, c.id, o.pack_points(gs, c), o.pack_points(hs, c), ugh, values,
                                                 o.pack_field(gammas, c.n), n_bits, seed_rand=11, seed_chal=22, tamper=True)
     assert not bad["ok"]
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n,deg", [(1, 1), (2, 2), (16, 13), (64, 64)])
+def test_poly_commit_open_verify_halo(ctx, c, n, deg):
+    """src/poly_commit/mod.rs: prove (45-119) equals the oracle message by message (L, R, a, r,
+    folded generator), verify (121-173) and lazy_verify (264-315) accept, a wrong evaluation
+    is rejected, and two deferred checks folded with fold_todos_* (228-262) verify as one
+    opening (the identities of the reference's poly_commit tests, src/poly_commit/mod.rs:317-420)"""
+    from bulletproofs_amd import host_mirror
+
+    rng = o.SplitMix64(4242 + n + c.id)
+    pts = o.gen_points_arith(n + 1, rng.field(c.n), rng.field(c.n), c)
+    gs, h = pts[:n], pts[n]
+    coeffs = rng.scalars(deg, c.n)
+    r, x = rng.field(c.n), rng.field(c.n)
+    hg = np.stack([np.concatenate([o.pack_field([P[0]], c.p)[0], o.pack_field([P[1]], c.p)[0]]) for P in (h, c.g)])
+    res = host_mirror.poly_commit_roundtrip(ctx, c.id, o.pack_points(gs, c), hg, o.pack_field(coeffs, c.n),
+                                            o.pack_field([r], c.n), o.pack_field([x], c.n), seed_rand=5, seed_chal=6)
+    com, ev = o.poly_commit_statement(c, gs, h, coeffs, r, x)
+    Ls, Rs, a, rr, g, ui = o.poly_commit_prove(c, gs, h, coeffs, r, x, 5, 6)
+    assert xyz_to_affine(res["commitment"], c) == com
+    assert o.unpack_field(res["evaluation"], c.n)[0] == ev
+    for j in range(len(Ls)):
+        assert xyz_to_affine(res["L"][j], c) == Ls[j] and xyz_to_affine(res["R"][j], c) == Rs[j], j
+    assert o.unpack_field(res["a"], c.n)[0] == a and o.unpack_field(res["r"], c.n)[0] == rr
+    got_g = None if res["g"][8] else (o.unpack_field(res["g"][0:4], c.p)[0], o.unpack_field(res["g"][4:8], c.p)[0])
+    assert got_g == g
+    assert o.poly_commit_check(c, gs, h, com, ev, x, Ls, Rs, a, rr, 6)[0]  # the oracle's verifier accepts the same proof
+    assert res["verify_ok"] and res["lazy_ok"] and res["halo_ok"]
+    bad = host_mirror.poly_commit_roundtrip(ctx, c.id, o.pack_points(gs, c), hg, o.pack_field(coeffs, c.n),
+                                            o.pack_field([r], c.n), o.pack_field([x], c.n), seed_rand=5, seed_chal=6,
+                                            tamper=True, halo=False)
+    assert not bad["verify_ok"] and not bad["lazy_ok"]
