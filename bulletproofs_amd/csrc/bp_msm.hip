@@ -63,9 +63,7 @@ static inline int ilog2_floor(size_t n) {
 // points into 2^(t-1) buckets, which then need a deep tree of partial sums.
 int msm_choose_window(size_t n) {
   int l = ilog2_floor(n ? n : 1);
-  if (l >= 17) return 16;
-  if (l >= 14) return 13;
-  if (l == 13) return 11;
+  if (l >= 18) return 16;
   if (l >= 9) return 8;
   return 4;
 }
@@ -767,6 +765,39 @@ __global__ __launch_bounds__(1024) void k_bucket_heavy_entries(const u32* __rest
   }
 }
 
+// Joins the chunk sums of every bucket with `lanes` lanes per bucket (strided serial
+// additions, then a shuffle tree): for plans whose buckets all hold many chunks (narrow
+// windows on mid-sized inputs), where one lane per bucket would be a long chain and one
+// block per bucket a waste.
+template <class C>
+__global__ __launch_bounds__(256) void k_bucket_finish_tree(const u32* __restrict__ nch,
+                                                            const u32* __restrict__ choff, size_t nbt,
+                                                            size_t nc_cap, const u32* __restrict__ chunk_sums,
+                                                            int lanes, u32* __restrict__ buckets) {
+  using F = typename C::Fq;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t b = t / (size_t)lanes;
+  const u32 sub = (u32)(t % (size_t)lanes);
+  const bool live = b < nbt;
+  u32 n = 0, off = 0;
+  if (live) {
+    n = nch[b];
+    off = choff[b];
+  }
+  const bool direct = n == 1;  // k_chunk_sums wrote the bucket itself
+  if (direct) n = 0;
+  Xyzz acc = xyzz_identity<F>();
+  for (u32 k = sub; k < n; k += (u32)lanes) {
+    Xyzz v = xyzz_load_soa(chunk_sums, nc_cap, off + k);
+    xyzz_add<F>(acc, v);
+  }
+  for (int o = lanes >> 1; o > 0; o >>= 1) {
+    Xyzz other = xyzz_shfl_down(acc, o, lanes);
+    if ((int)sub < o) xyzz_add<F>(acc, other);
+  }
+  if (live && !direct && sub == 0) xyzz_store_soa(buckets, nbt, b, acc);
+}
+
 // ---- 5'. window value for 64..256 buckets in one block -------------------------------------
 // V = sum_{m=1}^{NB} m * B_{m-1}.  Slot m of an LDS array holds B_{m-1} (slot 0 the
 // identity; m = NB is kept aside).  A binary sum tree is built in place: after step t the
@@ -1048,15 +1079,24 @@ static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspac
                                              ws.chunk_sums));
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;
-    DISPATCH_CURVE(curve, {
-      hipLaunchKernelGGL(k_bucket_finish<C>, dim3((unsigned)((nbt + 127) / 128)), dim3(128), 0, st, ws.nch, ws.choff,
-                         nbt, plan.nc_cap, ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
-      hipLaunchKernelGGL(k_bucket_heavy<C>, dim3(256), dim3(256), 0, st, ws.nch, ws.choff, nbt, plan.nc_cap,
-                         ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
-    });
+    // expected chunks per bucket; beyond a handful every bucket gets a lane group
+    const size_t per_bucket_chunks = plan.entries / (nbt ? nbt : 1) / plan.chunk;
+    if (per_bucket_chunks > kFinishSerial / 2 && nbt * 16 <= ((size_t)1 << 22)) {
+      const int lanes = 16;
+      DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_bucket_finish_tree<C>, dim3((unsigned)((nbt * lanes + 255) / 256)),
+                                               dim3(256), 0, st, ws.nch, ws.choff, nbt, plan.nc_cap, ws.chunk_sums,
+                                               lanes, ws.buckets));
+    } else {
+      DISPATCH_CURVE(curve, {
+        hipLaunchKernelGGL(k_bucket_finish<C>, dim3((unsigned)((nbt + 127) / 128)), dim3(128), 0, st, ws.nch, ws.choff,
+                           nbt, plan.nc_cap, ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
+        hipLaunchKernelGGL(k_bucket_heavy<C>, dim3(256), dim3(256), 0, st, ws.nch, ws.choff, nbt, plan.nc_cap,
+                           ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
+      });
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  if (plan.small && plan.n_buckets >= 64 && plan.n_buckets <= 256) {
+  if (plan.n_buckets >= 64 && plan.n_buckets <= 256) {
     int log_nb = 0;
     while ((1u << log_nb) < plan.n_buckets) log_nb++;
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_window_reduce_small<C>, dim3((unsigned)plan.n_windows),

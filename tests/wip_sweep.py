@@ -54,9 +54,9 @@ BX, BY = dev(np.tile(bx, (reps, 1))), dev(np.tile(by, (reps, 1)))
 K = dev(rand_field(big))
 for logn in logs:
     n = 1 << logn
-    for c in range(max(4, logn - 7), 17):
+    for c in ([int(v) for v in os.environ['SWEEP_C'].split(',')] if os.environ.get('SWEEP_C') else range(max(4, logn - 7), 17)):
         row = []
-        for seg in (0, 4, 8, 16):
+        for seg in ((0,) if os.environ.get('SWEEP_C') else (0, 4, 8, 16)):
             if seg:
                 os.environ["BP_MSM_SEG_LEN"] = str(seg)
             else:
@@ -67,4 +67,4 @@ for logn in logs:
                 ctx.msm_dev(C, BX.data_ptr(), BY.data_ptr(), None, K.data_ptr(), n)
                 ts.append(ctx.last_kernel_ms(1))
             row.append(min(ts))
-        print(f"log2n={logn} c={c:2d}  auto={row[0]:.3f}  seg4={row[1]:.3f}  seg8={row[2]:.3f}  seg16={row[3]:.3f}", flush=True)
+        print(f"log2n={logn} c={c:2d}  " + "  ".join(f"{v:.3f}" for v in row), flush=True)
