@@ -105,6 +105,7 @@ struct MsmPlan {
   int seg_len;    // buckets per reduction segment
   u32 n_segs;     // per window
   bool small;     // one-launch front end (digits, counting sort, bounds) per window, tree accumulation
+  bool mid;       // sliced counting sort (three launches), tree accumulation
 };
 
 int msm_choose_window(size_t n);

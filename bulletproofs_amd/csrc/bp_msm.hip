@@ -51,6 +51,10 @@ constexpr int kSmallThreads = 1024;
 constexpr int kSmallIters = 17;
 constexpr size_t kSmallMaxPoints = (size_t)kSmallThreads * kSmallIters;
 constexpr u32 kSmallMaxBuckets = 4096;
+// the sliced counting sort for mid-sized problems (k_mid_*)
+constexpr int kMidIters = 8;
+constexpr u32 kMidSlice = kSmallThreads * kMidIters;
+constexpr u32 kMidMaxBuckets = 256;
 
 static inline int ilog2_floor(size_t n) {
   int l = 0;
@@ -140,7 +144,10 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   if ((p.entries >> 21) > p.chunk) p.chunk = (u32)((p.entries >> 21) > 4096 ? 4096 : (p.entries >> 21));
   p.nc_cap = p.entries / p.chunk + nbt + 1;
   p.small = small_ok && p.n_buckets <= kSmallMaxBuckets;
-  if (p.small) {
+  // narrow windows on more points than one block sorts: the sliced counting sort
+  p.mid = !p.small && n_total > 0 && p.n_buckets >= 64 && p.n_buckets <= kMidMaxBuckets && n_total <= ((size_t)1 << 20) &&
+          !getenv("BP_MSM_NO_MID");
+  if (p.small || p.mid) {
     // every window owns a fixed range of n_total slots of the sorted-entry array
     size_t need = (size_t)p.n_windows * n_total * sizeof(u32);
     if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
@@ -470,6 +477,180 @@ __global__ __launch_bounds__(1024) void k_small_front(
     const u32 gb = wid * n_buckets + b, st = slice + off[b];
     bucket_start[gb] = st;
     bucket_end[gb] = st + hist[b];
+  }
+}
+
+// ---- 1-3 for mid-sized problems with narrow windows ---------------------------------------
+// The same counting sort over more points than one block can hold: the points are cut into
+// slices of kMidSlice; block (slice, window) takes the digits of its slice for window w of
+// both groups, ranks them inside the slice with LDS atomics and leaves bucket | rank | sign
+// per (window, point) plus its histogram (k_mid_count); one block per (group, window) turns
+// the histograms into bucket bounds and per-slice offsets (k_mid_offsets); the first grid
+// again scatters the entries (k_mid_scatter).  Three launches instead of about thirty.
+
+__device__ __forceinline__ void window_carry_consts(u32 w, int c, u32* thr, u32* msk) {
+  // A value's signed digits d_j in (-half, half] below window w represent its low c*w bits
+  // without a carry exactly when those bits are <= T_w = half * sum_{j<w} 2^(c*j).
+  for (int t = 0; t < 8; t++) thr[t] = msk[t] = 0;
+  for (u32 j = 0; j < w; j++) {
+    u32 bit = j * (u32)c + (u32)c - 1;
+    if (bit < 256) thr[bit >> 5] |= 1u << (bit & 31);
+  }
+  u32 low = w * (u32)c;
+  for (u32 bit = 0; bit < low && bit < 256; bit++) msk[bit >> 5] |= 1u << (bit & 31);
+}
+
+__device__ __forceinline__ u32 digit_group_of(const DigitGroups& sel, size_t i, size_t n0, size_t n01) {
+  const bool second = i >= n0;
+  const u32 half_sel = second ? sel.half1 : sel.half0;
+  if (i >= n01) return (u32)(i - n01);
+  if (half_sel == 0) return second ? sel.lo1 : sel.lo0;
+  size_t li = second ? i - n0 : i;
+  bool up = (li % (2 * (size_t)half_sel)) >= half_sel;
+  return up ? (second ? sel.hi1 : sel.hi0) : (second ? sel.lo1 : sel.lo0);
+}
+
+// tmp word: bucket (12 bits; n_buckets = no entry) | rank inside the slice << 12 | sign << 31
+template <class C>
+__global__ __launch_bounds__(1024) void k_mid_count(
+    const u32* __restrict__ s0, const uint8_t* __restrict__ inf0, size_t n0, const u32* __restrict__ s1,
+    const uint8_t* __restrict__ inf1, size_t n1, const u32* __restrict__ x0, const u32* __restrict__ y0,
+    const u32* __restrict__ x1, const u32* __restrict__ y1, u32* __restrict__ packed, DigitGroups sel, int c,
+    int group_windows, int groups, u32 n_buckets, u32 n_slices, u32* __restrict__ tmp, u32* __restrict__ ghist,
+    u32* __restrict__ heavy_count) {
+  using Fr = typename C::Fr;
+  __shared__ u32 hist[2 * kMidMaxBuckets];
+  __shared__ u32 thr[8], msk[8];
+  const u32 slice = blockIdx.x, w = blockIdx.y;
+  const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
+  const u32 half = 1u << (c - 1), mask = (1u << c) - 1;
+  for (u32 b = threadIdx.x; b < 2 * n_buckets; b += kSmallThreads) hist[b] = 0;
+  if (threadIdx.x == 0) {
+    window_carry_consts(w, c, thr, msk);
+    if (slice == 0 && w == 0) *heavy_count = 0;
+  }
+  __syncthreads();
+  const u32 invalid = n_buckets;
+  const int bit0 = (int)(w * (u32)c), limb = bit0 >> 5, sh = bit0 & 31;
+  for (int it = 0; it < kMidIters; it++) {
+    size_t i = (size_t)slice * kMidSlice + (size_t)it * kSmallThreads + threadIdx.x;
+    if (i >= n) continue;
+    const bool is_extra = i >= n01, second = i >= n0;
+    const u32 grp = digit_group_of(sel, i, n0, n01);
+    if (w == 0) {
+      const u32* px = second ? x1 + (i - n0) * 8 : x0 + i * 8;
+      const u32* py = second ? y1 + (i - n0) * 8 : y0 + i * 8;
+      if (is_extra) {
+        px = sel.extra_xy[i - n01];
+        py = px + 8;
+      }
+      fe_store(packed + i * 16, fe_load(px));
+      fe_store(packed + i * 16 + 8, fe_load(py));
+    }
+    const u32* sp = second ? s1 + (i - n0) * 8 : s0 + i * 8;
+    if (is_extra) sp = sel.extra_s[i - n01];
+    const bool is_inf = is_extra ? false : (second ? (inf1 && inf1[i - n0]) : (inf0 && inf0[i]));
+    Fe k = fe_from_mont<Fr>(fe_load(sp));
+    u32 flip = 0;
+    {
+      Fe nk = fe_neg<Fr>(k);
+      bool gt = false, decided = false;
+#pragma unroll
+      for (int t = 7; t >= 0; t--) {
+        if (!decided && k.v[t] != nk.v[t]) {
+          gt = k.v[t] > nk.v[t];
+          decided = true;
+        }
+      }
+      if (gt) {
+        k = nk;
+        flip = 0x80000000u;
+      }
+    }
+    u32 carry = 0;
+    {
+      bool gt = false, decided = false;
+#pragma unroll
+      for (int t = 7; t >= 0; t--) {
+        u32 kv = k.v[t] & msk[t], tv = thr[t];
+        if (!decided && kv != tv) {
+          gt = kv > tv;
+          decided = true;
+        }
+      }
+      carry = gt ? 1u : 0u;
+    }
+    u32 raw = 0;
+    if (limb < 8) {
+      u32 lo = 0, hi = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        lo = (t == limb) ? k.v[t] : lo;
+        hi = (t == limb + 1) ? k.v[t] : hi;
+      }
+      unsigned long long two = ((unsigned long long)hi << 32) | lo;
+      raw = (u32)(two >> sh) & mask;
+    }
+    u32 v = raw + carry, key, sign = flip;
+    if (v > half) {
+      u32 mag = (1u << c) - v;
+      key = mag ? mag - 1 : invalid;
+      sign ^= 0x80000000u;
+    } else {
+      key = v ? v - 1 : invalid;
+    }
+    if (is_inf) key = invalid;
+    u32 rank = 0;
+    if (key != invalid) rank = atomicAdd(&hist[grp * n_buckets + key], 1u);
+    tmp[(size_t)w * n + i] = key | (rank << 12) | sign;
+  }
+  __syncthreads();
+  for (u32 q = threadIdx.x; q < (u32)groups * n_buckets; q += kSmallThreads) {
+    const u32 g = q / n_buckets, b = q % n_buckets;
+    const u32 wid = g * (u32)group_windows + w;
+    ghist[((size_t)wid * n_slices + slice) * n_buckets + b] = hist[q];
+  }
+}
+
+// one block of n_buckets lanes per (group, window): ghist[wid][s][b] becomes the number of
+// entries of bucket b in the slices before s; the bucket bounds follow from the totals
+__global__ __launch_bounds__(256) void k_mid_offsets(u32* __restrict__ ghist, u32 n_buckets, u32 n_slices, size_t n,
+                                                     u32* __restrict__ bucket_start, u32* __restrict__ bucket_end) {
+  __shared__ u32 tot[kMidMaxBuckets];
+  const u32 wid = blockIdx.x, b = threadIdx.x;
+  u32 run = 0;
+  for (u32 s = 0; s < n_slices; s++) {
+    size_t at = ((size_t)wid * n_slices + s) * n_buckets + b;
+    u32 v = ghist[at];
+    ghist[at] = run;
+    run += v;
+  }
+  tot[b] = run;
+  __syncthreads();
+  u32 before = 0;
+  for (u32 q = 0; q < b; q++) before += tot[q];
+  const u32 st = wid * (u32)n + before;  // window wid owns [wid*n, (wid+1)*n) of the sorted entries
+  bucket_start[(size_t)wid * n_buckets + b] = st;
+  bucket_end[(size_t)wid * n_buckets + b] = st + run;
+}
+
+__global__ __launch_bounds__(1024) void k_mid_scatter(const u32* __restrict__ tmp, const u32* __restrict__ ghist,
+                                                      const u32* __restrict__ bucket_start, DigitGroups sel,
+                                                      size_t n0, size_t n1, int group_windows, u32 n_buckets,
+                                                      u32 n_slices, int wshift, u32* __restrict__ sorted_vals) {
+  const u32 slice = blockIdx.x, w = blockIdx.y;
+  const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
+  for (int it = 0; it < kMidIters; it++) {
+    size_t i = (size_t)slice * kMidSlice + (size_t)it * kSmallThreads + threadIdx.x;
+    if (i >= n) continue;
+    const u32 t = tmp[(size_t)w * n + i];
+    const u32 key = t & 0xfffu;
+    if (key >= n_buckets) continue;
+    const u32 rank = (t >> 12) & 0x7ffffu, sign = t & 0x80000000u;
+    const u32 wid = digit_group_of(sel, i, n0, n01) * (u32)group_windows + w;
+    const u32 pos = bucket_start[(size_t)wid * n_buckets + key] +
+                    ghist[((size_t)wid * n_slices + slice) * n_buckets + key] + rank;
+    sorted_vals[pos] = (u32)i | (wid << wshift) | sign;
   }
 }
 
@@ -1019,6 +1200,23 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
   }
+  if (plan.mid) {
+    const u32 n_slices = (u32)((n + kMidSlice - 1) / kMidSlice);
+    u32* tmp_words = ws.keys_a;  // group_windows * n words
+    u32* ghist = ws.keys_b;      // n_windows * n_slices * n_buckets words
+    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_mid_count<C>, dim3(n_slices, (unsigned)plan.group_windows),
+                                             dim3(kSmallThreads), 0, st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x,
+                                             p0.y, p1.x, p1.y, ws.packed, sel, plan.c, plan.group_windows, plan.groups,
+                                             plan.n_buckets, n_slices, tmp_words, ghist, ws.heavy_count));
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_mid_offsets, dim3((unsigned)plan.n_windows), dim3(plan.n_buckets), 0, st, ghist, plan.n_buckets,
+                       n_slices, n, ws.bucket_start, ws.bucket_end);
+    hipLaunchKernelGGL(k_mid_scatter, dim3(n_slices, (unsigned)plan.group_windows), dim3(kSmallThreads), 0, st, tmp_words,
+                       ghist, ws.bucket_start, sel, p0.n, p1.n, plan.group_windows, plan.n_buckets, n_slices, plan.wshift,
+                       ws.vals_b);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
+  }
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_digits<C>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                            st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, plan.c,
                                            plan.group_windows, plan.n_buckets, plan.wshift, ws.keys_a, ws.vals_a, p0.x, p0.y, p1.x, p1.y,
@@ -1058,14 +1256,19 @@ static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspac
   hipError_t e;
   const u32 idx_mask = (1u << plan.wshift) - 1u;
   if (ev_acc0 && (e = hipEventRecord(ev_acc0, st)) != hipSuccess) return e;
-  if (plan.small) {
-    // lanes per bucket: as many as keep the launch at about one wave per SIMD
+  if (plan.small || plan.mid) {
+    // lanes per bucket: as many as keep the launch at about one wave per SIMD, and at least
+    // one per 32 expected entries
     int lanes = 64;
     while (lanes > 1 && nbt * (size_t)lanes > 65536) lanes >>= 1;
+    const size_t per_bucket = plan.n_total / (size_t)plan.groups / plan.n_buckets;
+    while (lanes < 64 && (size_t)lanes * 32 < per_bucket) lanes <<= 1;
+    u32 heavy_from = (u32)(16 * lanes);
+    if (heavy_from < 4 * per_bucket) heavy_from = (u32)(4 * per_bucket);
     const size_t tree_threads = nbt * (size_t)lanes;
     DISPATCH_CURVE(curve, {
       hipLaunchKernelGGL(k_bucket_tree<C>, dim3((unsigned)((tree_threads + 255) / 256)), dim3(256), 0, st, ws.packed,
-                         ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, lanes, (u32)(16 * lanes), idx_mask, ws.buckets,
+                         ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, lanes, heavy_from, idx_mask, ws.buckets,
                          ws.heavy, ws.heavy_count);
       hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3(256), dim3(1024), 0, st, ws.packed, ws.vals_b,
                          ws.bucket_start, ws.bucket_end, nbt, idx_mask, ws.buckets, ws.heavy, ws.heavy_count);
