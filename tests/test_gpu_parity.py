@@ -227,6 +227,28 @@ def test_msm_full_size_properties(ctx, coracle):
     assert r3 == o.add(r1, r2, c)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("n", [17407, 17408, 17409, 40000])
+def test_msm_path_boundaries(ctx, coracle, c, n):
+    """sizes on both sides of the switch between the one-block counting sort (<= 17408
+    points) and the sliced one, with identity bases and zero / +-1 scalars mixed in"""
+    px, py = seeded_points(coracle, c, n, 31 + n, 977)
+    ints, K = random_scalars(c, n, n)
+    special = o.pack_field([0, 1, c.n - 1, 2, c.n - 2], c.n)
+    K[100:105] = special
+    K[n - 5:] = special
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[[7, 8192, n - 1]] = 1
+    exp = coracle.msm(c.id, (px, py, inf), K, 8)
+    assert np.array_equal(ctx.msm_unchecked(c.id, (px, py, inf), K), exp)
+    try:
+        for w in (7, 9):  # short top windows: many entries in few buckets
+            ctx.set_msm_window(w)
+            assert np.array_equal(ctx.msm_unchecked(c.id, (px, py, inf), K), exp), w
+    finally:
+        ctx.set_msm_window(0)
+
+
 def test_msm_beyond_baseline_size(ctx, coracle):
     """2^23 points (8 copies of 2^20): sum_j <K_j, P> == <sum_j K_j, P>.  At this size the
     accumulation chunks are longer than at 2^20, whose result the closed form pins."""
@@ -469,6 +491,56 @@ def test_ipa_resident_scaled_with_u(ctx, c, variant):
     if variant == 0:
         assert o.unpack_points(*H, c) == hs_cur
     assert o.unpack_field(A, c.n) == a_cur and o.unpack_field(B, c.n) == b_cur
+    s.free()
+    bases.free()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_ipa_mid_size_rounds_with_u(ctx, coracle, variant):
+    """n = 2^14 (the sliced counting sort with two output groups and the extra point u):
+    L and R of the first rounds equal the C oracle's MSM over the folded generators plus
+    c*u, and the final generators equal <s-vector, gs>, <s-vector^-1, hs>"""
+    c = o.SECP256K1
+    n, k = 1 << 14, 14
+    gx, gy = seeded_points(coracle, c, n, 17, 19)
+    hx, hy = seeded_points(coracle, c, n, 900001, 23)
+    _, A = random_scalars(c, n, 41)
+    _, B = random_scalars(c, n, 42)
+    _, CH = random_scalars(c, k, 43)
+    CHI = ctx.batch_inversion(c.id, CH)
+    u = o.scalar_mul(1234567, c.g, c)
+    ux, uy, _ = o.pack_points([u], c)
+    bases = ctx.register_bases(c.id, (np.concatenate([gx, hx]), np.concatenate([gy, hy]), None))
+    s = ctx.ipa_begin_resident(bases, variant, 0, n, A, B)
+    s.set_u(np.concatenate([ux[0], uy[0]]))
+    for j in range(k):
+        L, R, cl, cr = s.round_lr()
+        if j < 2:
+            (g2, h2, a_cur, b_cur) = s.read() if j else ((gx, gy, None), (hx, hy, None), A, B)
+            m = len(a_cur) // 2
+            if variant == 0:
+                lb = (np.concatenate([g2[0][m:], h2[0][:m]]), np.concatenate([g2[1][m:], h2[1][:m]]), None)
+                ls = np.concatenate([a_cur[:m], b_cur[m:]])
+                rb = (np.concatenate([g2[0][:m], h2[0][m:]]), np.concatenate([g2[1][:m], h2[1][m:]]), None)
+                rs = np.concatenate([a_cur[m:], b_cur[:m]])
+            else:
+                lb, ls = (g2[0][m:], g2[1][m:], None), a_cur[:m]
+                rb, rs = (g2[0][:m], g2[1][:m], None), a_cur[m:]
+            ecl = coracle.inner_product(c.id, a_cur[:m], b_cur[m:])
+            ecr = coracle.inner_product(c.id, a_cur[m:], b_cur[:m])
+            assert np.array_equal(cl, ecl) and np.array_equal(cr, ecr)
+            eL = o.add(xyz_to_affine(coracle.msm(c.id, lb, ls, 8), c), o.scalar_mul(o.unpack_field(ecl, c.n)[0], u, c), c)
+            eR = o.add(xyz_to_affine(coracle.msm(c.id, rb, rs, 8), c), o.scalar_mul(o.unpack_field(ecr, c.n)[0], u, c), c)
+            assert xyz_to_affine(L, c) == eL and xyz_to_affine(R, c) == eR, j
+        s.round_fold(CH[j:j + 1], CHI[j:j + 1])
+    G, H, Af, Bf = s.read()
+    ss = ctx.s_vector(c.id, CH, CHI)
+    eg = xyz_to_affine(coracle.msm(c.id, (gx, gy, None), ss, 8), c)
+    assert o.unpack_points(*G, c) == [eg]
+    if variant == 0:
+        ssi = ctx.s_vector(c.id, CHI, CH)
+        eh = xyz_to_affine(coracle.msm(c.id, (hx, hy, None), ssi, 8), c)
+        assert o.unpack_points(*H, c) == [eh]
     s.free()
     bases.free()
 
