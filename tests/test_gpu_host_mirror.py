@@ -70,7 +70,7 @@ def test_ipa_prove_verify_roundtrip(ctx, c, n):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
-@pytest.mark.parametrize("m,n_bits", [(2, 8), (4, 16)])
+@pytest.mark.parametrize("m,n_bits", [(1, 64), (2, 8), (4, 16)])
 def test_aggregated_range_proof(ctx, c, m, n_bits):
     """src/range/aggregate.rs:313-344 (prove -> verify) with seeded randomness and
     challenges: every prover message equals the oracle's, the verifier's deferred MSM

@@ -1,3 +1,5 @@
+"""Arithmetic micro-benchmarks (field multiply, add/sub, XYZZ mixed add, Jacobian doubling) through
+bp_microbench; prints rates per launch size.  usage (GPU box): python tools/microbench.py"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import bulletproofs_amd as bp

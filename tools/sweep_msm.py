@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Tuning sweep (not collected by pytest): MSM device time over window width and
-reduction segment length.  usage: python tests/wip_sweep.py [log2n ...]"""
+"""Tuning sweep: MSM device time over window width and
+reduction segment length.  usage: [SWEEP_C=8,16] python tools/sweep_msm.py [log2n ...]"""
 import os
 import sys
 

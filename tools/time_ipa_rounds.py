@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Scratch timing (not collected by pytest): per-call wall time of the IPA session at small n."""
+"""per-call wall time of the IPA session at small n."""
 import os
 import sys
 import time
