@@ -217,5 +217,26 @@ inline HXyzz hx_combine_windows(const uint64_t* win, int n_windows, int c) {
   return acc;
 }
 
+// Two independent combinations in lockstep: the two dependency chains interleave in the
+// core's out-of-order window, which nearly doubles the throughput of this latency-bound loop.
+template <class F>
+inline void hx_combine_windows2(const uint64_t* win_a, const uint64_t* win_b, int n_windows, int c, HXyzz* out_a,
+                                HXyzz* out_b) {
+  HXyzz a = hx_identity<F>(), b = hx_identity<F>();
+  for (int w = n_windows - 1; w >= 0; w--) {
+    for (int k = 0; k < c; k++) {
+      a = hx_dbl<F>(a);
+      b = hx_dbl<F>(b);
+    }
+    HXyzz pa, pb;
+    memcpy(&pa, win_a + (size_t)w * 16, 128);
+    memcpy(&pb, win_b + (size_t)w * 16, 128);
+    a = hx_add<F>(a, pa);
+    b = hx_add<F>(b, pb);
+  }
+  *out_a = a;
+  *out_b = b;
+}
+
 }  // namespace host
 }  // namespace bp

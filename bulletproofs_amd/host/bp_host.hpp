@@ -116,6 +116,74 @@ struct PointOps {
   }
 };
 
+// ---- fixed-base multiplication for the CRS points used one at a time (g, h, u) ------------
+// table[w][d-1] = d * 2^(8w) * P in affine coordinates (w < 32, d = 1..255, 522 KB): a
+// scalar multiplication is then at most 32 mixed additions instead of 256 doublings and
+// ~128 additions.  Built once per CRS.
+template <class Fq, class Fr>
+struct FixedBase {
+  std::vector<HFe> tx, ty;
+  bool ready = false;
+
+  static void madd(HXyzz& p, const HFe& x2, const HFe& y2) {  // madd-2008-s, a = 0
+    if (hx_is_identity(p)) { p.x = x2; p.y = y2; p.zz = h_one<Fq>(); p.zzz = h_one<Fq>(); return; }
+    HFe u2 = h_mul<Fq>(x2, p.zz), s2 = h_mul<Fq>(y2, p.zzz);
+    HFe pd = h_sub<Fq>(u2, p.x), rd = h_sub<Fq>(s2, p.y);
+    if (h_is_zero(pd)) {
+      HXyzz q; q.x = x2; q.y = y2; q.zz = h_one<Fq>(); q.zzz = h_one<Fq>();
+      p = h_is_zero(rd) ? hx_dbl<Fq>(q) : hx_identity<Fq>();
+      return;
+    }
+    HFe pp = h_sqr<Fq>(pd), ppp = h_mul<Fq>(pd, pp), q = h_mul<Fq>(p.x, pp);
+    HFe x3 = h_sub<Fq>(h_sub<Fq>(h_sqr<Fq>(rd), ppp), h_dbl<Fq>(q));
+    HFe y3 = h_sub<Fq>(h_mul<Fq>(rd, h_sub<Fq>(q, x3)), h_mul<Fq>(p.y, ppp));
+    p.zz = h_mul<Fq>(p.zz, pp); p.zzz = h_mul<Fq>(p.zzz, ppp); p.x = x3; p.y = y3;
+  }
+
+  void build(const Affine& pt) {
+    ready = false;
+    if (pt.inf) return;
+    const size_t total = 32 * 255;
+    std::vector<HXyzz> pts(total);
+    HXyzz base = PointOps<Fq, Fr>::lift(pt);
+    for (int w = 0; w < 32; w++) {
+      HXyzz cur = base;
+      for (int d = 1; d <= 255; d++) {
+        pts[(size_t)w * 255 + d - 1] = cur;
+        cur = hx_add<Fq>(cur, base);
+      }
+      base = cur;  // 256 * base
+    }
+    // batch inversion of the zzz coordinates (none is zero: the order is prime and > 2^254)
+    std::vector<HFe> pre(total);
+    HFe run = h_one<Fq>();
+    for (size_t i = 0; i < total; i++) { pre[i] = run; run = h_mul<Fq>(run, pts[i].zzz); }
+    HFe inv = h_inv<Fq>(run);
+    tx.resize(total); ty.resize(total);
+    for (size_t i = total; i-- > 0;) {
+      HFe i3 = h_mul<Fq>(inv, pre[i]);
+      inv = h_mul<Fq>(inv, pts[i].zzz);
+      HFe t = h_mul<Fq>(pts[i].zz, i3);  // 1/zz = (zz/zzz)^2
+      tx[i] = h_mul<Fq>(pts[i].x, h_sqr<Fq>(t));
+      ty[i] = h_mul<Fq>(pts[i].y, i3);
+    }
+    ready = true;
+  }
+
+  // k * P (k in Montgomery form); the identity when the base is the identity
+  HXyzz mul(const Scalar& k_mont) const {
+    HXyzz acc = hx_identity<Fq>();
+    if (!ready) return acc;
+    HFe km; memcpy(km.v, k_mont.l, 32);
+    HFe k = h_from_mont<Fr>(km);
+    for (int w = 0; w < 32; w++) {
+      unsigned d = (unsigned)((k.v[w >> 3] >> ((w & 7) * 8)) & 0xff);
+      if (d) madd(acc, tx[(size_t)w * 255 + d - 1], ty[(size_t)w * 255 + d - 1]);
+    }
+    return acc;
+  }
+};
+
 // ---- Msm: src/msm.rs:8-88 ----------------------------------------------------------
 template <class Fq, class Fr, int CURVE>
 class Msm {

@@ -31,6 +31,7 @@ struct PolyCommit {
     std::vector<Affine> gs;
     Affine h, gen;
     bp_bases* bases = nullptr;
+    FixedBase<Fq, Fr> h_tab, gen_tab;  // multiples of h and of the generator (built by register_bases)
   };
   struct Statement {  // src/poly_commit/types.rs:104-108
     Projective commitment;
@@ -39,6 +40,7 @@ struct PolyCommit {
 
   static void register_bases(bp_ctx* ctx, Crs& crs) {
     size_t n = crs.gs.size();
+    crs.h_tab.build(crs.h); crs.gen_tab.build(crs.gen);
     std::vector<uint64_t> x(4 * n), y(4 * n);
     std::vector<uint8_t> inf(n);
     for (size_t i = 0; i < n; i++) { memcpy(&x[4 * i], crs.gs[i].x, 32); memcpy(&y[4 * i], crs.gs[i].y, 32); inf[i] = crs.gs[i].inf; }
@@ -64,7 +66,7 @@ struct PolyCommit {
     st.x = x;
     Projective g;
     check(ctx, bp_msm_resident(ctx, crs.bases, 0, n, coeffs[0].l, g.xyz), "bp_msm_resident");        // :141
-    st.commitment = P::lower(hx_add<Fq>(P::lift(g), P::mul(P::lift(crs.h), r)));                      // :142-143
+    st.commitment = P::lower(hx_add<Fq>(P::lift(g), crs.h_tab.mul(r)));                               // :142-143
     std::vector<Scalar> pw(n);
     check(ctx, bp_powers(ctx, CURVE, x.l, n, pw[0].l), "bp_powers");
     check(ctx, bp_inner_product(ctx, CURVE, coeffs[0].l, pw[0].l, n, st.evaluation.l), "bp_inner_product");  // :145
@@ -76,14 +78,14 @@ struct PolyCommit {
                     RandomSource& rng, PolyProof& proof) {
     const size_t n = crs.gs.size();
     coeffs.resize(n, S::zero());
-    Affine u = P::to_affine(P::lower(P::mul(P::lift(crs.gen), t.verifier_scalar())));   // :55-58
+    Affine u = P::to_affine(P::lower(crs.gen_tab.mul(t.verifier_scalar())));             // :55-58
     std::vector<Scalar> b(n);
     check(ctx, bp_powers(ctx, CURVE, st.x.l, n, b[0].l), "bp_powers");                   // :65
     bp_ipa* s = nullptr;
     check(ctx, bp_ipa_begin_resident(ctx, crs.bases, BP_IPA_POLYCOMMIT, 0, 0, coeffs[0].l, b[0].l, n, &s),
           "bp_ipa_begin_resident");
     Todo todo;
-    HXyzz h = P::lift(crs.h), ux = P::lift(u);
+    HXyzz ux = P::lift(u);
     try {
       const bool u_on_device = !u.inf;
       if (u_on_device) {
@@ -95,8 +97,8 @@ struct PolyCommit {
         Scalar l_j = rng.scalar(), r_j = rng.scalar();                                  // :75
         Projective lm, rm; Scalar cl, cr;
         check(ctx, bp_ipa_round_lr(s, lm.xyz, rm.xyz, cl.l, cr.l), "bp_ipa_round_lr");  // :78,80 / :83,85
-        HXyzz left = hx_add<Fq>(P::lift(lm), P::mul(h, l_j));                           // :79
-        HXyzz right = hx_add<Fq>(P::lift(rm), P::mul(h, r_j));                          // :84
+        HXyzz left = hx_add<Fq>(P::lift(lm), crs.h_tab.mul(l_j));                       // :79
+        HXyzz right = hx_add<Fq>(P::lift(rm), crs.h_tab.mul(r_j));                      // :84
         if (!u_on_device) { left = hx_add<Fq>(left, P::mul(ux, cl)); right = hx_add<Fq>(right, P::mul(ux, cr)); }
         Projective lr[2] = {P::lower(left), P::lower(right)};
         t.prover_points(lr, 2);                                                         // :89
@@ -147,7 +149,7 @@ struct PolyCommit {
   }
 
   static void replay(const Crs& crs, const PolyProof& proof, Transcript& t, Affine& u, std::vector<Scalar>& ui) {
-    u = P::to_affine(P::lower(P::mul(P::lift(crs.gen), t.verifier_scalar())));          // :132-135
+    u = P::to_affine(P::lower(crs.gen_tab.mul(t.verifier_scalar())));                   // :132-135
     for (size_t j = 0; j < proof.L.size(); j++) {
       Projective lr[2] = {proof.L[j], proof.R[j]};
       t.prover_points(lr, 2);

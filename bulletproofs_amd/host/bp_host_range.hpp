@@ -36,6 +36,7 @@ struct RangeAggregate {
     Affine g, h;
     size_t n = 0;            // N = n_bits * m actually used
     bp_bases* gh = nullptr;  // gs[0..N) || hs[0..N)
+    FixedBase<Fq, Fr> g_tab, h_tab, u_tab;  // multiples of g, h, ipa.u (built by register_bases)
   };
 
   static void register_bases(bp_ctx* ctx, Crs& crs, size_t n) {
@@ -45,6 +46,7 @@ struct RangeAggregate {
       memcpy(&x[4 * (n + i)], crs.ipa.hs[i].x, 32); memcpy(&y[4 * (n + i)], crs.ipa.hs[i].y, 32);
     }
     crs.n = n;
+    crs.g_tab.build(crs.g); crs.h_tab.build(crs.h); crs.u_tab.build(crs.ipa.u);
     check(ctx, bp_bases_register(ctx, CURVE, x.data(), y.data(), nullptr, 2 * n, &crs.gh), "bp_bases_register");
   }
 
@@ -98,11 +100,10 @@ struct RangeAggregate {
     std::vector<Scalar> s_l(n), s_r(n);
     for (auto& v : s_l) v = rng.scalar();                    // :68-73
     for (auto& v : s_r) v = rng.scalar();
-    HXyzz h = P::lift(crs.h), g = P::lift(crs.g);
     RangeProof pr;
     tr.mark("bits, blinders");
-    pr.a = P::lower(hx_add<Fq>(P::mul(h, alpha), P::lift(msm_gh(ctx, crs, a_l, a_r))));   // :81
-    pr.s = P::lower(hx_add<Fq>(P::mul(h, rho), P::lift(msm_gh(ctx, crs, s_l, s_r))));     // :82
+    pr.a = P::lower(hx_add<Fq>(crs.h_tab.mul(alpha), P::lift(msm_gh(ctx, crs, a_l, a_r))));   // :81
+    pr.s = P::lower(hx_add<Fq>(crs.h_tab.mul(rho), P::lift(msm_gh(ctx, crs, s_l, s_r))));     // :82
     tr.mark("A, S commitments");
     Projective as[2] = {pr.a, pr.s};
     t.prover_points(as, 2);                                  // :85
@@ -127,8 +128,8 @@ struct RangeAggregate {
     Scalar tao1 = rng.scalar(), tao2 = rng.scalar();         // :121-122
     // t(X) = <l(X), r(X)>: t1 = <l0,r1> + <l1,r0>, t2 = <l1,r1>   (:125, src/range/types.rs:98-117)
     Scalar t1 = S::add(dot(ctx, l0, r1), dot(ctx, s_l, r0)), t2 = dot(ctx, s_l, r1);
-    pr.tt1 = P::lower(hx_add<Fq>(P::mul(g, t1), P::mul(h, tao1)));  // :126
-    pr.tt2 = P::lower(hx_add<Fq>(P::mul(g, t2), P::mul(h, tao2)));  // :127
+    pr.tt1 = P::lower(hx_add<Fq>(crs.g_tab.mul(t1), crs.h_tab.mul(tao1)));  // :126
+    pr.tt2 = P::lower(hx_add<Fq>(crs.g_tab.mul(t2), crs.h_tab.mul(tao2)));  // :127
     tr.mark("t1, t2, T1, T2");
     Projective tt[2] = {pr.tt1, pr.tt2};
     t.prover_points(tt, 2);                                  // :129
@@ -154,7 +155,7 @@ struct RangeAggregate {
     t.prover_scalars(msg, 3);                                // :159
     // ipa::extended::prove (src/ipa/extended.rs:15-35) over gs, hs', u' = x'*u
     Scalar xe = t.verifier_scalar();
-    Affine u2 = P::to_affine(P::lower(P::mul(P::lift(crs.ipa.u), xe)));
+    Affine u2 = P::to_affine(P::lower(crs.u_tab.mul(xe)));
     tr.mark("l, r, t_hat, y^-i, u'");
     pr.ipa = I::prove_resident(ctx, crs.gh, 0, n, y_inv_pows.data(), u2, l, r, t);  // :166
     tr.mark("ipa rounds");
@@ -196,8 +197,7 @@ struct RangeAggregate {
     }
     Projective vz;
     check(ctx, bp_msm(ctx, CURVE, vx.data(), vy.data(), vi.data(), zs.data(), m, vz.xyz), "bp_msm");  // :226
-    HXyzz hh = P::lift(crs.h), gg = P::lift(crs.g);
-    HXyzz lhs = hx_add<Fq>(P::mul(gg, sub(pr.t_hat, delta)), P::mul(hh, pr.tao_x));
+    HXyzz lhs = hx_add<Fq>(crs.g_tab.mul(sub(pr.t_hat, delta)), crs.h_tab.mul(pr.tao_x));
     HXyzz rhs = hx_add<Fq>(hx_add<Fq>(P::lift(vz), P::mul(P::lift(pr.tt1), x)), P::mul(P::lift(pr.tt2), S::mul(x, x)));
     HXyzz neg_rhs = rhs;
     neg_rhs.y = h_neg<Fq>(rhs.y);
@@ -225,11 +225,10 @@ struct RangeAggregate {
     check(ctx, bp_vec_op(ctx, CURVE, BP_VEC_HADAMARD, hsc[0].l, y_inv_pows[0].l, nullptr, n, hsc_scaled[0].l), "hadamard");
     Projective base = msm_gh(ctx, crs, gsc, hsc_scaled);                       // :259 (same group element)
     HXyzz p = hx_add<Fq>(hx_add<Fq>(P::lift(pr.a), P::mul(P::lift(pr.s), x)), P::lift(base));
-    p = hx_add<Fq>(p, P::mul(hh, S::neg(pr.mu)));                              // :264
+    p = hx_add<Fq>(p, crs.h_tab.mul(S::neg(pr.mu)));                           // :264
     // ipa::extended::verify_aux over the unscaled CRS (src/ipa/extended.rs:54-70) ...
     Scalar xe = t.verifier_scalar();
-    HXyzz u = P::lift(crs.ipa.u);
-    Projective p_stmt = P::lower(hx_add<Fq>(p, P::mul(u, S::mul(xe, pr.t_hat))));
+    Projective p_stmt = P::lower(hx_add<Fq>(p, crs.u_tab.mul(S::mul(xe, pr.t_hat))));
     M msm = I::verify_aux(ctx, crs.ipa, p_stmt, n, pr.ipa, t);
     std::vector<Affine> uu{crs.ipa.u};
     std::vector<Scalar> xx{xe};
