@@ -91,10 +91,12 @@ SIGNATURES = {
     "bp_ipa_round_lr": (ci, [vp, vp, vp, vp, vp]),
     "bp_ipa_round_fold": (ci, [vp, vp, vp]),
     "bp_ipa_len": (sz, [vp]),
+    "bp_bases_precompute": (ci, [vp]),
     "bp_msm_resident_s_vector": (ci, [vp, vp, sz, vp, vp, sz, vp]),
     "bp_ipa_begin_resident": (ci, [vp, vp, ci, sz, sz, vp, vp, sz, C.POINTER(vp)]),
     "bp_ipa_scale_h": (ci, [vp, vp]),
     "bp_ipa_set_u": (ci, [vp, vp]),
+    "bp_ipa_set_u_resident": (ci, [vp, sz, vp]),
     "bp_ipa_read": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "bp_ipa_free": (None, [vp]),
     "bp_bench_int_mad_peak": (ci, [vp, ci, C.POINTER(C.c_double)]),

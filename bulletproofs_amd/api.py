@@ -245,6 +245,11 @@ class Bases:
     def __len__(self):
         return lib.bp_bases_len(self.h)
 
+    def precompute(self):
+        """window tables for this base set (bp_bases_precompute)"""
+        self.ctx._chk(lib.bp_bases_precompute(self.h))
+        return self
+
     def msm(self, scalars, offset=0, n=None):
         s = _f(scalars)
         if n is None:
@@ -310,6 +315,11 @@ class IpaSession:
         """u as 8 u64 (x|y): round_lr then returns L, R including c_l*u, c_r*u"""
         u = None if u_xy is None else np.ascontiguousarray(u_xy, dtype=np.uint64).reshape(8)
         self.ctx._chk(lib.bp_ipa_set_u(self.h, _p(u)))
+
+    def set_u_resident(self, u_index, factor):
+        """u = factor * bases[u_index] (bp_ipa_set_u_resident)"""
+        f = _f(factor)
+        self.ctx._chk(lib.bp_ipa_set_u_resident(self.h, u_index, _p(f)))
 
     def round_fold(self, x, x_inv):
         x, xi = _f(x), _f(x_inv)

@@ -51,7 +51,12 @@ struct bp_bases {
   u32* x;
   u32* y;
   uint8_t* inf;
+  u32* tab = nullptr;  // window tables (bp_bases_precompute): kTableWindows * n records of 64 bytes
 };
+
+// MSMs over at most this many points use the window tables of a base set that has them;
+// beyond, the 16-bit-window pipeline does half the additions and wins
+constexpr size_t kTableMaxPoints = (size_t)1 << 17;
 
 // The prover never folds the generator vectors.  It keeps the vectors it was given and, per
 // generator, the product of the challenges that folding would have multiplied it by (cg, ch);
@@ -73,6 +78,13 @@ struct bp_ipa {
   u32 *eg = nullptr, *eh = nullptr;  // n0 cross-term scalars each
   u32* u_xy = nullptr;               // the point u (x|y) when has_u
   bool has_u = false;
+  // u given as factor * bases[u_index] (bp_ipa_set_u_resident): its MSM scalars are
+  // factor * c_l, factor * c_r and it can be addressed through the base set's window tables
+  bool u_scaled = false;
+  size_t u_index = 0;
+  FeArg u_factor{};
+  const bp_bases* res = nullptr;     // generators live in this base set (not owned)
+  size_t g_off = 0, h_off = 0;
   u32* dots = nullptr;               // partial sums and results of the two inner products
   // folded generators, materialised on demand (n0/2 points each)
   u32 *fgx = nullptr, *fgy = nullptr, *fhx = nullptr, *fhy = nullptr;
@@ -182,9 +194,9 @@ void finish_windows(int curve, const uint64_t* win, int n_windows, int c, uint64
 
 // device phase of an MSM: leaves plan->n_windows XYZZ window sums in S_WINDOWS
 int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, MsmPlan* plan,
-               u32** d_windows, int groups = 1, const MsmExtra* extra = nullptr) {
+               u32** d_windows, int groups = 1, const MsmExtra* extra = nullptr, const MsmTable* table = nullptr) {
   size_t n = p0.n + p1.n + (extra ? 2 : 0);
-  hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan);
+  hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan, table ? table->stride : 0);
   if (e != hipSuccess) return fail(ctx, BP_E_ARG, "msm plan (n too large?)", e);
   MsmWorkspace ws{};
   void* p;
@@ -213,7 +225,7 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
   CHK(reserve(ctx, S_SEG_GROUPS, plan->seg_group_bytes, &p)); ws.seg_groups = (u32*)p;
   CHK(reserve(ctx, S_WINDOWS, plan->win_bytes, &p)); ws.windows = (u32*)p;
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  e = msm_run(curve, p0, p1, extra, *plan, ws, ctx->stream, ctx->ev[2], ctx->ev[3]);
+  e = msm_run(curve, p0, p1, extra, *plan, ws, ctx->stream, ctx->ev[2], ctx->ev[3], table);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "msm_run", e);
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   *d_windows = ws.windows;
@@ -226,10 +238,11 @@ void msm_collect_times(bp_ctx* ctx, bool had_points) {
   if (had_points && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[0] = ms;
 }
 
-int msm_full(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, uint64_t out_xyz[12]) {
+int msm_full(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, uint64_t out_xyz[12],
+             const MsmTable* table = nullptr) {
   MsmPlan plan;
   u32* d_win = nullptr;
-  CHK(msm_device(ctx, curve, p0, p1, &plan, &d_win));
+  CHK(msm_device(ctx, curve, p0, p1, &plan, &d_win, 1, nullptr, table));
   CHK(reserve_pinned(ctx, plan.win_bytes));
   HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -394,7 +407,26 @@ void bp_bases_free(bp_bases* b) {
   (void)hipFree(b->x);
   (void)hipFree(b->y);
   (void)hipFree(b->inf);
+  if (b->tab) (void)hipFree(b->tab);
   delete b;
+}
+
+int bp_bases_precompute(bp_bases* b) {
+  if (!b) return BP_E_ARG;
+  bp_ctx* ctx = b->ctx;
+  Guard g(ctx);
+  if (b->tab || b->n == 0) return BP_OK;
+  if ((size_t)kTableWindows * b->n >= ((size_t)1 << 30)) return fail(ctx, BP_E_ARG, "bp_bases_precompute: base set too large");
+  u32* tab = nullptr;
+  HIPCHK(ctx, hipMalloc((void**)&tab, (size_t)kTableWindows * b->n * 64));
+  hipError_t e = launch_window_tables(b->curve, b->x, b->y, b->inf, b->n, kTableWindowBits, kTableWindows, tab, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(tab);
+    return fail(ctx, BP_E_HIP, "bp_bases_precompute", e);
+  }
+  b->tab = tab;
+  return BP_OK;
 }
 
 size_t bp_bases_len(const bp_bases* b) { return b ? b->n : 0; }
@@ -409,7 +441,9 @@ int bp_msm_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
   CHK(upload(ctx, S_IN3, scalars, n * 32, &ds));
   MsmPart p0{bases->x + offset * 8, bases->y + offset * 8, bases->inf + offset, (const u32*)ds, n};
   MsmPart p1{nullptr, nullptr, nullptr, nullptr, 0};
-  return msm_full(ctx, bases->curve, p0, p1, out_xyz);
+  p0.tab_offset = offset;
+  MsmTable table{bases->tab, bases->n};
+  return msm_full(ctx, bases->curve, p0, p1, out_xyz, bases->tab && n <= kTableMaxPoints ? &table : nullptr);
 }
 
 int bp_msm_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64_t* d_y, const uint8_t* d_inf,
@@ -753,7 +787,7 @@ IpaLayout ipa_layout(size_t n, bool has_h, bool owns_gens) {
   l.cg = take(n * 32); l.eg = take(n * 32);
   if (has_h) { l.ch = take(n * 32); l.eh = take(n * 32); }
   l.u = take(64);
-  l.dots = take((size_t)2 * (kDotBlocks + 1) * 32);
+  l.dots = take(((size_t)2 * kDotBlocks + 4) * 32);
   l.total = off;
   return l;
 }
@@ -818,6 +852,7 @@ int ipa_begin_common(bp_ctx* ctx, int curve, int variant, const bp_bases* res, s
     if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream);
   };
   if (res) {
+    s->res = res; s->g_off = g_off; s->h_off = h_off;
     s->gx = res->x + g_off * 8; s->gy = res->y + g_off * 8; s->ginf = res->inf + g_off;
     if (has_h) { s->hx = res->x + h_off * 8; s->hy = res->y + h_off * 8; s->hinf = res->inf + h_off; }
   } else {
@@ -909,10 +944,31 @@ int bp_ipa_set_u(bp_ipa* s, const uint64_t u_xy[8]) {
   bp_ctx* ctx = s->ctx;
   Guard g(ctx);
   s->has_u = false;
+  s->u_scaled = false;
   if (!u_xy) return BP_OK;
   HIPCHK(ctx, hipMemcpyAsync(s->u_xy, u_xy, 64, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   s->has_u = true;
+  return BP_OK;
+}
+
+int bp_ipa_set_u_resident(bp_ipa* s, size_t u_index, const uint64_t factor[4]) {
+  if (!s || !factor) return BP_E_ARG;
+  bp_ctx* ctx = s->ctx;
+  if (!s->res) return fail(ctx, BP_E_STATE, "bp_ipa_set_u_resident: session was not begun over a registered base set");
+  if (u_index >= s->res->n) return fail(ctx, BP_E_ARG, "bp_ipa_set_u_resident: index outside the base set");
+  Guard g(ctx);
+  // x|y side by side for plans that read the point itself
+  HIPCHK(ctx, hipMemcpyAsync(s->u_xy, s->res->x + u_index * 8, 32, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(s->u_xy + 8, s->res->y + u_index * 8, 32, hipMemcpyDeviceToDevice, ctx->stream));
+  uint8_t inf = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&inf, s->res->inf + u_index, 1, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  s->has_u = s->u_scaled = false;
+  if (inf) return BP_OK;  // a multiple of the identity adds nothing
+  s->u_index = u_index;
+  s->u_factor = to_arg(factor);
+  s->has_u = s->u_scaled = true;
   return BP_OK;
 }
 
@@ -928,11 +984,14 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
   const u32 *a_lo = s->a, *a_hi = s->a + h * 8, *b_lo = s->b, *b_hi = s->b + h * 8;
   // c_l = <a_lo, b_hi>, c_r = <a_hi, b_lo> (src/ipa/mod.rs:42,58); they stay on the device as
   // the scalars of u when one is set
+  // dots: partial sums of the two products, then c_l, c_r, factor*c_l, factor*c_r
   u32* part_l = s->dots;
-  u32* part_r = part_l + (size_t)(kDotBlocks + 1) * 8;
-  u32 *d_cl = part_l + (size_t)kDotBlocks * 8, *d_cr = part_r + (size_t)kDotBlocks * 8;
+  u32* part_r = part_l + (size_t)kDotBlocks * 8;
+  u32 *d_cl = part_r + (size_t)kDotBlocks * 8, *d_cr = d_cl + 8, *d_scaled = d_cl + 16;
   hipError_t e = launch_inner_product(s->curve, a_lo, b_hi, h, part_l, d_cl, ctx->stream);
   if (e == hipSuccess) e = launch_inner_product(s->curve, a_hi, b_lo, h, part_r, d_cr, ctx->stream);
+  if (e == hipSuccess && s->has_u && s->u_scaled)
+    e = launch_vec_op(s->curve, BP_VEC_SCALE, d_cl, nullptr, s->u_factor, 2, d_scaled, ctx->stream);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "inner_product", e);
   e = launch_ipa_scalars(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, n0, h, s->eg, s->eh, ctx->stream);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_scalars", e);
@@ -948,9 +1007,23 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
     ph.sel_half = h; ph.group_lo = 0; ph.group_hi = 1;
   }
   MsmExtra extra{{s->u_xy, s->u_xy}, {d_cl, d_cr}};
+  if (s->u_scaled) {
+    extra.s[0] = d_scaled;
+    extra.s[1] = d_scaled + 8;
+    extra.tab_index[0] = extra.tab_index[1] = s->u_index;
+  }
+  // window tables of the base set, when it has them and u (if any) is one of its points
+  MsmTable table;
+  const MsmTable* use_table = nullptr;
+  if (s->res && s->res->tab && n0 * (has_h ? 2 : 1) + 2 <= kTableMaxPoints && (!s->has_u || s->u_scaled)) {
+    table = MsmTable{s->res->tab, s->res->n};
+    pg.tab_offset = s->g_off;
+    ph.tab_offset = s->h_off;
+    use_table = &table;
+  }
   MsmPlan plan;
   u32* d_win = nullptr;
-  CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2, s->has_u ? &extra : nullptr));
+  CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2, s->has_u ? &extra : nullptr, use_table));
   CHK(reserve_pinned(ctx, plan.win_bytes + 64));
   char* host = (char*)ctx->pinned;
   HIPCHK(ctx, hipMemcpyAsync(host, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1019,7 +1092,15 @@ int bp_ipa_read(bp_ipa* s, uint64_t* gx, uint64_t* gy, uint8_t* ginf, uint64_t* 
     }
     MsmPlan plan;
     u32* d_win = nullptr;
-    CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2));
+    MsmTable table;
+    const MsmTable* use_table = nullptr;
+    if (s->res && s->res->tab && n0 * (has_h ? 2 : 1) <= kTableMaxPoints) {
+      table = MsmTable{s->res->tab, s->res->n};
+      pg.tab_offset = s->g_off;
+      ph.tab_offset = s->h_off;
+      use_table = &table;
+    }
+    CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2, nullptr, use_table));
     CHK(reserve_pinned(ctx, plan.win_bytes));
     HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

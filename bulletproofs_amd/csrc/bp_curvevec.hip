@@ -128,6 +128,41 @@ hipError_t launch_scale_points(int curve, const u32* px, const u32* py, const ui
   return hipGetLastError();
 }
 
+// Window tables of a fixed base set: record (w, i) = 2^(c*w) * P_i as affine x|y (16 u32) at
+// index w*n + i.  With them an MSM over these bases needs one bucket set for all windows and
+// no doublings afterwards.  One lane per base; built once per base set.
+template <class C>
+__global__ __launch_bounds__(256) void k_window_tables(const u32* __restrict__ px, const u32* __restrict__ py,
+                                                       const uint8_t* __restrict__ pinf, size_t n, int c,
+                                                       int n_windows, u32* __restrict__ table) {
+  using F = typename C::Fq;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool inf = pinf && pinf[i];
+  Jac acc;
+  acc.x = fe_load(px + i * 8);
+  acc.y = fe_load(py + i * 8);
+  acc.z = fe_one<F>();
+  for (int w = 0; w < n_windows; w++) {
+    if (w)
+      for (int k = 0; k < c; k++) acc = jac_dbl<F>(acc);
+    Fe x = fe_zero(), y = fe_zero();
+    if (!inf) jac_to_affine<F>(acc, x, y);  // never the identity: the group order is an odd prime
+    u32* rec = table + ((size_t)w * n + i) * 16;
+    fe_store(rec, x);
+    fe_store(rec + 8, y);
+  }
+}
+
+hipError_t launch_window_tables(int curve, const u32* px, const u32* py, const uint8_t* pinf, size_t n, int c,
+                                int n_windows, u32* table, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_window_tables<C>, dim3(blocks), dim3(256), 0, st, px, py, pinf, n, c,
+                                           n_windows, table));
+  return hipGetLastError();
+}
+
 // Jacobian (X,Y,Z interleaved, 24 u32 per point) -> affine planes
 template <class C>
 __global__ __launch_bounds__(256) void k_normalize_jac(const u32* __restrict__ xyz, size_t n,

@@ -71,6 +71,9 @@ hipError_t launch_fold_generators2(int curve, const FoldJob& j0, const FoldJob& 
 hipError_t launch_scale_points(int curve, const u32* px, const u32* py, const uint8_t* pinf,
                                const u32* s, size_t n, u32* ox, u32* oy, uint8_t* oinf,
                                hipStream_t st);
+// table: n_windows * n records of 16 u32
+hipError_t launch_window_tables(int curve, const u32* px, const u32* py, const uint8_t* pinf, size_t n, int c,
+                                int n_windows, u32* table, hipStream_t st);
 hipError_t launch_normalize_jac(int curve, const u32* xyz, size_t n, u32* ox, u32* oy, uint8_t* oinf,
                                 hipStream_t st);
 
@@ -86,7 +89,16 @@ struct MsmPart {
   // (i mod 2*sel_half) >= sel_half and to group_lo when not (n must be a multiple of 2*sel_half).
   size_t sel_half = 0;
   u32 group_lo = 0, group_hi = 0;
+  size_t tab_offset = 0;  // table plans: index of this part's first point in the base set
 };
+
+// Window tables of a registered base set (launch_window_tables): record (w, j) at w*stride + j
+struct MsmTable {
+  const u32* rec = nullptr;
+  size_t stride = 0;
+};
+constexpr int kTableWindowBits = 8;
+constexpr int kTableWindows = 32;
 
 struct MsmPlan {
   int c;          // window bits
@@ -106,10 +118,12 @@ struct MsmPlan {
   u32 n_segs;     // per window
   bool small;     // one-launch front end (digits, counting sort, bounds) per window, tree accumulation
   bool mid;       // sliced counting sort (three launches), tree accumulation
+  bool tab;       // points come from window tables: all digit windows share one bucket set per group
+  int digit_windows;  // windows of the digit decomposition (= group_windows unless tab)
 };
 
 int msm_choose_window(size_t n);
-hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan);
+hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride = 0);
 
 struct MsmWorkspace {
   u32* packed;        // points as x|y pairs, 16 u32 each
@@ -141,13 +155,15 @@ struct MsmWorkspace {
 struct MsmExtra {
   const u32* xy[2];  // affine x|y, 16 u32, not the identity; extra e goes to group e
   const u32* s[2];   // Montgomery-form scalar, 8 u32
+  size_t tab_index[2] = {0, 0};  // table plans: index of the point in the base set
 };
 
 // Runs digits -> sort -> bucket accumulation -> bucket reduction; leaves W window
 // sums (XYZZ, 32 u32 each) in ws.windows.  ev_acc0/ev_acc1 (optional) bracket the
 // accumulation kernel.
 hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExtra* extra, const MsmPlan& plan,
-                   const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1);
+                   const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1,
+                   const MsmTable* table = nullptr);
 // sums n_parts arrays of n_windows XYZZ points window by window into out (n_windows XYZZ)
 hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int n_windows, u32* out,
                                  hipStream_t st);

@@ -78,24 +78,32 @@ static int key_bits_for(u32 max_key) {
   return b;
 }
 
-hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan) {
+hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride) {
   MsmPlan p{};
   if (groups < 1 || groups > 2) return hipErrorInvalidValue;
   p.groups = groups;
+  p.tab = table_stride != 0 && n_total > 0;
   p.c = (c_override >= 2 && c_override <= 20) ? c_override : msm_choose_window(n_total / groups);
   // below kSmallMaxPoints the one-launch front end and the tree kernels apply, and 8-bit
   // windows (128 buckets, no short top window) are fastest from 2^9 points up
   const bool small_ok = n_total > 0 && n_total <= kSmallMaxPoints && !getenv("BP_MSM_NO_SMALL");
   if (small_ok && !(c_override >= 2 && c_override <= 20)) p.c = n_total / groups >= 512 ? 8 : 4;
+  if (p.tab) p.c = kTableWindowBits;
   // k_digits maps a scalar k > r/2 to r - k (and negates the point), so digits
   // come from a value below 2^255 (secp256k1) or 2^254 (Vesta); one more bit
   // absorbs the carry of the signed recoding.
   const int value_bits = curve == BP_VESTA ? 254 : 255;
   p.group_windows = (value_bits + 1 + p.c - 1) / p.c;
+  p.digit_windows = p.group_windows;
+  if (p.tab) {
+    // every digit window lands in the one bucket set of its group: one output "window" per group
+    if (p.digit_windows > kTableWindows) return hipErrorInvalidValue;
+    p.group_windows = 1;
+  }
   p.n_windows = p.group_windows * groups;
   p.n_buckets = 1u << (p.c - 1);
   p.n_total = n_total;
-  p.entries = (size_t)p.group_windows * n_total;
+  p.entries = (size_t)p.digit_windows * n_total;
   if (p.entries >= (1ull << 31)) return hipErrorInvalidValue;
   // Buckets per reduction lane: the reduction is a dependent chain of 2*seg_len additions
   // plus a multiplication by the segment offset, so short segments win as long as the
@@ -119,6 +127,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   while ((1 << wbits) < p.n_windows) wbits++;
   p.wshift = 31 - wbits;
   if (n_total >= ((size_t)1 << p.wshift)) return hipErrorInvalidValue;
+  if (p.tab && (size_t)kTableWindows * table_stride >= ((size_t)1 << p.wshift)) return hipErrorInvalidValue;
   u32 max_key = p.n_buckets;
   hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
       nullptr, tmp, nullptr, nullptr, nullptr, nullptr, p.entries ? p.entries : 1, 0,
@@ -143,13 +152,14 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   // number of partial sums per bucket small
   if ((p.entries >> 21) > p.chunk) p.chunk = (u32)((p.entries >> 21) > 4096 ? 4096 : (p.entries >> 21));
   p.nc_cap = p.entries / p.chunk + nbt + 1;
-  p.small = small_ok && p.n_buckets <= kSmallMaxBuckets;
+  p.small = small_ok && p.n_buckets <= kSmallMaxBuckets && !p.tab;
   // narrow windows on more points than one block sorts: the sliced counting sort
-  p.mid = !p.small && n_total > 0 && p.n_buckets >= 64 && p.n_buckets <= kMidMaxBuckets && n_total <= ((size_t)1 << 20) &&
-          !getenv("BP_MSM_NO_MID");
+  p.mid = p.tab || (!p.small && n_total > 0 && p.n_buckets >= 64 && p.n_buckets <= kMidMaxBuckets &&
+                    n_total <= ((size_t)1 << 20) && !getenv("BP_MSM_NO_MID"));
   if (p.small || p.mid) {
-    // every window owns a fixed range of n_total slots of the sorted-entry array
-    size_t need = (size_t)p.n_windows * n_total * sizeof(u32);
+    // every output window owns a fixed range of slots of the sorted-entry array: n_total, or
+    // all of a group's digit windows together for table plans
+    size_t need = (size_t)p.n_windows * (p.tab ? p.entries : n_total) * sizeof(u32);
     if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
   }
   p.nch_bytes = ((nbt + 2) * sizeof(u32) + 255) & ~(size_t)255;
@@ -178,6 +188,7 @@ struct DigitGroups {
   u32 n_extra;
   const u32* extra_xy[2];
   const u32* extra_s[2];
+  u32 extra_tab[2];  // table plans: index of the extra point in the base set
 };
 
 template <class C>
@@ -516,8 +527,10 @@ __global__ __launch_bounds__(1024) void k_mid_count(
     const u32* __restrict__ s0, const uint8_t* __restrict__ inf0, size_t n0, const u32* __restrict__ s1,
     const uint8_t* __restrict__ inf1, size_t n1, const u32* __restrict__ x0, const u32* __restrict__ y0,
     const u32* __restrict__ x1, const u32* __restrict__ y1, u32* __restrict__ packed, DigitGroups sel, int c,
-    int group_windows, int groups, u32 n_buckets, u32 n_slices, u32* __restrict__ tmp, u32* __restrict__ ghist,
-    u32* __restrict__ heavy_count) {
+    int group_windows, int groups, u32 n_buckets, u32 n_slices, int tab, u32* __restrict__ tmp,
+    u32* __restrict__ ghist, u32* __restrict__ heavy_count) {
+  // tab != 0: the points come from window tables, every digit window feeds the one bucket
+  // set of its group, and (window, slice) pairs take the place of slices
   using Fr = typename C::Fr;
   __shared__ u32 hist[2 * kMidMaxBuckets];
   __shared__ u32 thr[8], msk[8];
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(1024) void k_mid_count(
     if (i >= n) continue;
     const bool is_extra = i >= n01, second = i >= n0;
     const u32 grp = digit_group_of(sel, i, n0, n01);
-    if (w == 0) {
+    if (w == 0 && !tab) {
       const u32* px = second ? x1 + (i - n0) * 8 : x0 + i * 8;
       const u32* py = second ? y1 + (i - n0) * 8 : y0 + i * 8;
       if (is_extra) {
@@ -607,14 +620,16 @@ __global__ __launch_bounds__(1024) void k_mid_count(
   __syncthreads();
   for (u32 q = threadIdx.x; q < (u32)groups * n_buckets; q += kSmallThreads) {
     const u32 g = q / n_buckets, b = q % n_buckets;
-    const u32 wid = g * (u32)group_windows + w;
-    ghist[((size_t)wid * n_slices + slice) * n_buckets + b] = hist[q];
+    const u32 wid = tab ? g : g * (u32)group_windows + w;
+    const u32 sl = tab ? w * n_slices + slice : slice;
+    const u32 ns = tab ? (u32)gridDim.y * n_slices : n_slices;
+    ghist[((size_t)wid * ns + sl) * n_buckets + b] = hist[q];
   }
 }
 
 // one block of n_buckets lanes per (group, window): ghist[wid][s][b] becomes the number of
 // entries of bucket b in the slices before s; the bucket bounds follow from the totals
-__global__ __launch_bounds__(256) void k_mid_offsets(u32* __restrict__ ghist, u32 n_buckets, u32 n_slices, size_t n,
+__global__ __launch_bounds__(256) void k_mid_offsets(u32* __restrict__ ghist, u32 n_buckets, u32 n_slices, size_t stride,
                                                      u32* __restrict__ bucket_start, u32* __restrict__ bucket_end) {
   __shared__ u32 tot[kMidMaxBuckets];
   const u32 wid = blockIdx.x, b = threadIdx.x;
@@ -629,7 +644,7 @@ __global__ __launch_bounds__(256) void k_mid_offsets(u32* __restrict__ ghist, u3
   __syncthreads();
   u32 before = 0;
   for (u32 q = 0; q < b; q++) before += tot[q];
-  const u32 st = wid * (u32)n + before;  // window wid owns [wid*n, (wid+1)*n) of the sorted entries
+  const u32 st = wid * (u32)stride + before;  // output window wid owns [wid*stride, (wid+1)*stride)
   bucket_start[(size_t)wid * n_buckets + b] = st;
   bucket_end[(size_t)wid * n_buckets + b] = st + run;
 }
@@ -637,8 +652,12 @@ __global__ __launch_bounds__(256) void k_mid_offsets(u32* __restrict__ ghist, u3
 __global__ __launch_bounds__(1024) void k_mid_scatter(const u32* __restrict__ tmp, const u32* __restrict__ ghist,
                                                       const u32* __restrict__ bucket_start, DigitGroups sel,
                                                       size_t n0, size_t n1, int group_windows, u32 n_buckets,
-                                                      u32 n_slices, int wshift, u32* __restrict__ sorted_vals) {
+                                                      u32 n_slices, int wshift, int tab, size_t tab_stride,
+                                                      size_t tab_off0, size_t tab_off1,
+                                                      u32* __restrict__ sorted_vals) {
   const u32 slice = blockIdx.x, w = blockIdx.y;
+  const u32 sl = tab ? w * n_slices + slice : slice;
+  const u32 ns = tab ? (u32)gridDim.y * n_slices : n_slices;
   const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
   for (int it = 0; it < kMidIters; it++) {
     size_t i = (size_t)slice * kMidSlice + (size_t)it * kSmallThreads + threadIdx.x;
@@ -647,10 +666,16 @@ __global__ __launch_bounds__(1024) void k_mid_scatter(const u32* __restrict__ tm
     const u32 key = t & 0xfffu;
     if (key >= n_buckets) continue;
     const u32 rank = (t >> 12) & 0x7ffffu, sign = t & 0x80000000u;
-    const u32 wid = digit_group_of(sel, i, n0, n01) * (u32)group_windows + w;
-    const u32 pos = bucket_start[(size_t)wid * n_buckets + key] +
-                    ghist[((size_t)wid * n_slices + slice) * n_buckets + key] + rank;
-    sorted_vals[pos] = (u32)i | (wid << wshift) | sign;
+    const u32 grp = digit_group_of(sel, i, n0, n01);
+    const u32 wid = tab ? grp : grp * (u32)group_windows + w;
+    const u32 pos = bucket_start[(size_t)wid * n_buckets + key] + ghist[((size_t)wid * ns + sl) * n_buckets + key] + rank;
+    // table plans address record (w, base index); the others the packed copy of point i
+    size_t idx = i;
+    if (tab) {
+      size_t base_index = i >= n01 ? sel.extra_tab[i - n01] : (i >= n0 ? tab_off1 + (i - n0) : tab_off0 + i);
+      idx = (size_t)w * tab_stride + base_index;
+    }
+    sorted_vals[pos] = (u32)idx | (wid << wshift) | sign;
   }
 }
 
@@ -914,10 +939,11 @@ __global__ __launch_bounds__(1024) void k_bucket_heavy_entries(const u32* __rest
                                                                const u32* __restrict__ heavy_count) {
   using F = typename C::Fq;
   __shared__ u32 lds[16 * 32];
-  const u32 count = *heavy_count;
+  // heavy == null: every bucket, in order
+  const u32 count = heavy ? *heavy_count : (u32)nbt;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (u32 q = blockIdx.x; q < count; q += gridDim.x) {
-    const u32 b = heavy[q];
+    const u32 b = heavy ? heavy[q] : q;
     const u32 s = start[b], e = end[b];
     Xyzz acc = xyzz_identity<F>();
     for (u32 p = s + threadIdx.x; p < e; p += blockDim.x) {
@@ -1159,10 +1185,11 @@ hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int
 }
 
 static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st,
-                               hipEvent_t ev_acc0, hipEvent_t ev_acc1);
+                               hipEvent_t ev_acc0, hipEvent_t ev_acc1, const u32* table_rec = nullptr);
 
 hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExtra* extra, const MsmPlan& plan,
-                   const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
+                   const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1,
+                   const MsmTable* table) {
   const size_t n = plan.n_total;
   const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
   hipError_t e;
@@ -1171,8 +1198,8 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     return hipMemsetAsync(ws.windows, 0, plan.win_bytes, st);
   }
   DigitGroups sel{(u32)p0.sel_half, (u32)p1.sel_half, p0.group_lo, p0.group_hi, p1.group_lo, p1.group_hi, 0,
-                  {nullptr, nullptr}, {nullptr, nullptr}};
-  if (plan.groups == 1) sel = DigitGroups{0, 0, 0, 0, 0, 0, 0, {nullptr, nullptr}, {nullptr, nullptr}};
+                  {nullptr, nullptr}, {nullptr, nullptr}, {0, 0}};
+  if (plan.groups == 1) sel = DigitGroups{0, 0, 0, 0, 0, 0, 0, {nullptr, nullptr}, {nullptr, nullptr}, {0, 0}};
   if (extra) {
     // one extra point per group, split parts only
     if (plan.groups != 2 || !p0.sel_half || (p1.n && !p1.sel_half) || n != p0.n + p1.n + 2) return hipErrorInvalidValue;
@@ -1180,6 +1207,7 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     for (int e = 0; e < 2; e++) {
       sel.extra_xy[e] = extra->xy[e];
       sel.extra_s[e] = extra->s[e];
+      sel.extra_tab[e] = (u32)extra->tab_index[e];
     }
   } else if (n != p0.n + p1.n) {
     return hipErrorInvalidValue;
@@ -1200,22 +1228,26 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
   }
+  if (plan.tab && (!table || !table->rec)) return hipErrorInvalidValue;
   if (plan.mid) {
     const u32 n_slices = (u32)((n + kMidSlice - 1) / kMidSlice);
-    u32* tmp_words = ws.keys_a;  // group_windows * n words
-    u32* ghist = ws.keys_b;      // n_windows * n_slices * n_buckets words
-    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_mid_count<C>, dim3(n_slices, (unsigned)plan.group_windows),
+    const int tab = plan.tab ? 1 : 0;
+    const u32 n_slices_eff = tab ? n_slices * (u32)plan.digit_windows : n_slices;
+    const size_t stride = tab ? plan.entries : n;  // sorted entries per output window
+    u32* tmp_words = ws.keys_a;  // digit_windows * n words
+    u32* ghist = ws.keys_b;      // n_windows * n_slices_eff * n_buckets words
+    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_mid_count<C>, dim3(n_slices, (unsigned)plan.digit_windows),
                                              dim3(kSmallThreads), 0, st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x,
                                              p0.y, p1.x, p1.y, ws.packed, sel, plan.c, plan.group_windows, plan.groups,
-                                             plan.n_buckets, n_slices, tmp_words, ghist, ws.heavy_count));
+                                             plan.n_buckets, n_slices, tab, tmp_words, ghist, ws.heavy_count));
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(k_mid_offsets, dim3((unsigned)plan.n_windows), dim3(plan.n_buckets), 0, st, ghist, plan.n_buckets,
-                       n_slices, n, ws.bucket_start, ws.bucket_end);
-    hipLaunchKernelGGL(k_mid_scatter, dim3(n_slices, (unsigned)plan.group_windows), dim3(kSmallThreads), 0, st, tmp_words,
+                       n_slices_eff, stride, ws.bucket_start, ws.bucket_end);
+    hipLaunchKernelGGL(k_mid_scatter, dim3(n_slices, (unsigned)plan.digit_windows), dim3(kSmallThreads), 0, st, tmp_words,
                        ghist, ws.bucket_start, sel, p0.n, p1.n, plan.group_windows, plan.n_buckets, n_slices, plan.wshift,
-                       ws.vals_b);
+                       tab, tab ? table->stride : 0, p0.tab_offset, p1.tab_offset, ws.vals_b);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
+    return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1, tab ? table->rec : nullptr);
   }
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_digits<C>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                            st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, plan.c,
@@ -1251,8 +1283,9 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
 
 // accumulation and reduction over a finished entry order and chunk table
 static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st,
-                               hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
+                               hipEvent_t ev_acc0, hipEvent_t ev_acc1, const u32* table_rec) {
   const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
+  const u32* points = table_rec ? table_rec : ws.packed;  // 64-byte x|y records the entries index
   hipError_t e;
   const u32 idx_mask = (1u << plan.wshift) - 1u;
   if (ev_acc0 && (e = hipEventRecord(ev_acc0, st)) != hipSuccess) return e;
@@ -1261,16 +1294,22 @@ static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspac
     // one per 32 expected entries
     int lanes = 64;
     while (lanes > 1 && nbt * (size_t)lanes > 65536) lanes >>= 1;
-    const size_t per_bucket = plan.n_total / (size_t)plan.groups / plan.n_buckets;
+    const size_t per_bucket = plan.entries / (nbt ? nbt : 1);
     while (lanes < 64 && (size_t)lanes * 32 < per_bucket) lanes <<= 1;
     u32 heavy_from = (u32)(16 * lanes);
     if (heavy_from < 4 * per_bucket) heavy_from = (u32)(4 * per_bucket);
     const size_t tree_threads = nbt * (size_t)lanes;
+    if (nbt <= 512 && per_bucket >= 512) {
+      // few buckets with many entries each (table plans on small inputs): a block per bucket
+      DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3((unsigned)nbt), dim3(1024), 0, st, points,
+                                               ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, idx_mask, ws.buckets,
+                                               (const u32*)nullptr, (const u32*)nullptr));
+    } else
     DISPATCH_CURVE(curve, {
-      hipLaunchKernelGGL(k_bucket_tree<C>, dim3((unsigned)((tree_threads + 255) / 256)), dim3(256), 0, st, ws.packed,
+      hipLaunchKernelGGL(k_bucket_tree<C>, dim3((unsigned)((tree_threads + 255) / 256)), dim3(256), 0, st, points,
                          ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, lanes, heavy_from, idx_mask, ws.buckets,
                          ws.heavy, ws.heavy_count);
-      hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3(256), dim3(1024), 0, st, ws.packed, ws.vals_b,
+      hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3(256), dim3(1024), 0, st, points, ws.vals_b,
                          ws.bucket_start, ws.bucket_end, nbt, idx_mask, ws.buckets, ws.heavy, ws.heavy_count);
     });
     if ((e = hipGetLastError()) != hipSuccess) return e;

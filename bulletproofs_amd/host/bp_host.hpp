@@ -306,27 +306,29 @@ struct Ipa {
   // bases[h_off..)), optionally with H_i scaled by h_scale[i] (the hs' of
   // src/range/aggregate.rs:148-153 without materialising them).
   static IpaProof prove_resident(bp_ctx* ctx, const bp_bases* bases, size_t g_off, size_t h_off, const Scalar* h_scale,
-                                 const Affine& u, const std::vector<Scalar>& a, const std::vector<Scalar>& b,
-                                 Transcript& t) {
+                                 size_t u_index, const Scalar& u_factor, const std::vector<Scalar>& a,
+                                 const std::vector<Scalar>& b, Transcript& t) {
+    // u = u_factor * bases[u_index]
     bp_ipa* s = nullptr;
     check(ctx, bp_ipa_begin_resident(ctx, bases, BP_IPA_BULLETPROOF, g_off, h_off, a[0].l, b[0].l, a.size(), &s),
           "bp_ipa_begin_resident");
-    if (h_scale) {
-      int rc = bp_ipa_scale_h(s, h_scale[0].l);
-      if (rc != BP_OK) { bp_ipa_free(s); check(ctx, rc, "bp_ipa_scale_h"); }
-    }
-    return prove_session(ctx, s, u, t);
+    int rc = h_scale ? bp_ipa_scale_h(s, h_scale[0].l) : BP_OK;
+    if (rc == BP_OK) rc = bp_ipa_set_u_resident(s, u_index, u_factor.l);
+    if (rc != BP_OK) { bp_ipa_free(s); check(ctx, rc, "bp_ipa_scale_h / bp_ipa_set_u_resident"); }
+    Affine none{};
+    none.inf = 1;  // u is already with the session
+    return prove_session(ctx, s, none, t, true);
   }
 
   // takes ownership of the session
-  static IpaProof prove_session(bp_ctx* ctx, bp_ipa* s, const Affine& u_aff, Transcript& t) {
+  static IpaProof prove_session(bp_ctx* ctx, bp_ipa* s, const Affine& u_aff, Transcript& t, bool u_is_set = false) {
     IpaProof proof;
     HXyzz u = P::lift(u_aff);
     try {
       // u*c_l and u*c_r ride in the device pass (two 256-bit scalar multiplications per
       // round would otherwise be done here on one host core)
-      const bool u_on_device = !u_aff.inf;
-      if (u_on_device) {
+      const bool u_on_device = u_is_set || !u_aff.inf;
+      if (u_on_device && !u_is_set) {
         uint64_t uxy[8];
         memcpy(uxy, u_aff.x, 32); memcpy(uxy + 4, u_aff.y, 32);
         check(ctx, bp_ipa_set_u(s, uxy), "bp_ipa_set_u");

@@ -35,19 +35,21 @@ struct RangeAggregate {
     typename I::Crs ipa;
     Affine g, h;
     size_t n = 0;            // N = n_bits * m actually used
-    bp_bases* gh = nullptr;  // gs[0..N) || hs[0..N)
+    bp_bases* gh = nullptr;  // gs[0..N) || hs[0..N) || ipa.u
     FixedBase<Fq, Fr> g_tab, h_tab, u_tab;  // multiples of g, h, ipa.u (built by register_bases)
   };
 
   static void register_bases(bp_ctx* ctx, Crs& crs, size_t n) {
-    std::vector<uint64_t> x(8 * n), y(8 * n);
+    std::vector<uint64_t> x(8 * n + 4), y(8 * n + 4);
+    std::vector<uint8_t> inf(2 * n + 1, 0);
     for (size_t i = 0; i < n; i++) {
       memcpy(&x[4 * i], crs.ipa.gs[i].x, 32); memcpy(&y[4 * i], crs.ipa.gs[i].y, 32);
       memcpy(&x[4 * (n + i)], crs.ipa.hs[i].x, 32); memcpy(&y[4 * (n + i)], crs.ipa.hs[i].y, 32);
     }
+    memcpy(&x[8 * n], crs.ipa.u.x, 32); memcpy(&y[8 * n], crs.ipa.u.y, 32); inf[2 * n] = crs.ipa.u.inf;
     crs.n = n;
     crs.g_tab.build(crs.g); crs.h_tab.build(crs.h); crs.u_tab.build(crs.ipa.u);
-    check(ctx, bp_bases_register(ctx, CURVE, x.data(), y.data(), nullptr, 2 * n, &crs.gh), "bp_bases_register");
+    check(ctx, bp_bases_register(ctx, CURVE, x.data(), y.data(), inf.data(), 2 * n + 1, &crs.gh), "bp_bases_register");
   }
 
   static Scalar from_u64(uint64_t v) { Scalar c{{v, 0, 0, 0}}; return S::to_mont(c); }
@@ -155,9 +157,9 @@ struct RangeAggregate {
     t.prover_scalars(msg, 3);                                // :159
     // ipa::extended::prove (src/ipa/extended.rs:15-35) over gs, hs', u' = x'*u
     Scalar xe = t.verifier_scalar();
-    Affine u2 = P::to_affine(P::lower(crs.u_tab.mul(xe)));
     tr.mark("l, r, t_hat, y^-i, u'");
-    pr.ipa = I::prove_resident(ctx, crs.gh, 0, n, y_inv_pows.data(), u2, l, r, t);  // :166
+    // u' = x' * u is bases[2N] with the factor x' (no scalar multiplication on the host)
+    pr.ipa = I::prove_resident(ctx, crs.gh, 0, n, y_inv_pows.data(), 2 * n, xe, l, r, t);  // :166
     tr.mark("ipa rounds");
     return pr;
   }

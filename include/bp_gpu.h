@@ -100,6 +100,17 @@ int bp_bases_register(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t*
                       const uint8_t* inf, size_t n, bp_bases** out);
 void bp_bases_free(bp_bases* b);
 size_t bp_bases_len(const bp_bases* b);
+/* Optional: builds window tables for a registered base set (2^(8w) * P for w < 32: 2 KiB per
+ * base, one lane per base, a few ms).  MSMs and IPA sessions over these bases with at most
+ * 2^17 points then put all windows into one bucket set per sum, and the host has no
+ * doublings left to do when it combines the result.  Results are unchanged.  It trades host
+ * time (about 0.08 ms per sum on a current server core) for longer dependent chains on the
+ * GPU (128 buckets with 32 times the entries each): measured on MI355X it is slower than the
+ * default path (IPA round at 2^12: 0.55 ms against 0.44 ms), so the drivers in
+ * bulletproofs_amd/host do not call it; it pays only where the host core is several times
+ * slower.  No counterpart in the reference (arkworks' msm_unchecked takes the bases fresh on
+ * every call). */
+int bp_bases_precompute(bp_bases* b);
 /* MSM over bases[offset .. offset+n) with host scalars (crs.gs[0..n] slices:
  * src/ipa/types.rs:81-82). */
 int bp_msm_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
@@ -212,6 +223,11 @@ int bp_ipa_scale_h(bp_ipa* s, const uint64_t* scale);
  * bp_ipa_round_lr returns L = c_l*u + <..>, R = c_r*u + <..> complete
  * (src/ipa/mod.rs:43,59; src/poly_commit/mod.rs:80,85) in the same device pass. */
 int bp_ipa_set_u(bp_ipa* s, const uint64_t u_xy[8]);
+/* As bp_ipa_set_u with u = factor * bases[u_index], for sessions begun with
+ * bp_ipa_begin_resident: the u' = x * crs.u of ipa::extended::prove
+ * (src/ipa/extended.rs:29-33) without a scalar multiplication; u is then reached through
+ * the base set's window tables when it has them. */
+int bp_ipa_set_u_resident(bp_ipa* s, size_t u_index, const uint64_t factor[4]);
 int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t c_l[4],
                     uint64_t c_r[4]);
 int bp_ipa_round_fold(bp_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]);

@@ -451,7 +451,8 @@ def test_ipa_final_generator_property(ctx, coracle, variant):
 
 @pytest.mark.parametrize("c", CURVES, ids=ids)
 @pytest.mark.parametrize("variant", [0, 1])
-def test_ipa_resident_scaled_with_u(ctx, c, variant):
+@pytest.mark.parametrize("mode", ["point", "index", "tables"])
+def test_ipa_resident_scaled_with_u(ctx, c, variant, mode):
     """generators from a registered base set, H scaled by y^-i, u folded into L and R:
     every round equals the oracle's ipa round over (gs, hs' = y^-i hs) plus c*u
     (src/range/aggregate.rs:148-166, src/ipa/mod.rs:40-73)"""
@@ -459,19 +460,25 @@ def test_ipa_resident_scaled_with_u(ctx, c, variant):
 
     n, k = 32, 5
     g, h, a, b, ch = ipa_inputs(c, n, 4242 + variant)
-    u = o.scalar_mul(987654321, c.g, c)
+    u0, factor = o.scalar_mul(987654321, c.g, c), 0x1234567890ABCDEF1234567890ABCDEF % c.n
+    u = o.scalar_mul(factor, u0, c)  # mode "point": u itself; otherwise factor * bases[2n]
     yinv = pow(31337, -1, c.n)
     scale = [pow(yinv, i, c.n) for i in range(n)]
     hsp = o.scale_points(h, scale, c) if variant == 0 else None
-    bases = ctx.register_bases(c.id, o.pack_points(g + h, c))
+    bases = ctx.register_bases(c.id, o.pack_points(g + h + [u0], c))
+    if mode == "tables":
+        bases.precompute()  # window tables: same results through one bucket set per sum
     s = ctx.ipa_begin_resident(bases, variant, 0, n, o.pack_field(a, c.n), o.pack_field(b, c.n))
     if variant == 0:
         s.scale_h(o.pack_field(scale, c.n))
     else:
         with pytest.raises(BpError):
             s.scale_h(o.pack_field(scale, c.n))
-    ux, uy, _ = o.pack_points([u], c)
-    s.set_u(np.concatenate([ux[0], uy[0]]))
+    if mode == "point":
+        ux, uy, _ = o.pack_points([u], c)
+        s.set_u(np.concatenate([ux[0], uy[0]]))
+    else:
+        s.set_u_resident(2 * n, o.pack_field([factor], c.n))
     gs_cur, hs_cur, a_cur, b_cur = list(g), (list(hsp) if hsp else list(h)), list(a), list(b)
     for j in range(k):
         L, R, cl, cr = s.round_lr()
@@ -563,3 +570,22 @@ def test_error_codes(ctx):
     assert e.value.code == -1
     with pytest.raises(BpError):
         ctx.set_msm_window(1)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("n", [1, 5, 300, 8192, 20000])
+def test_msm_window_tables(ctx, coracle, c, n):
+    """bp_bases_precompute: the MSM over a base set with window tables (one bucket set for all
+    windows, no doublings) equals the C oracle's, for whole sets and sub-ranges, with
+    identity bases and zero scalars"""
+    px, py = seeded_points(coracle, c, n, 555 + n, 13)
+    _, K = random_scalars(c, n, 7 * n)
+    inf = np.zeros(n, dtype=np.uint8)
+    if n > 4:
+        inf[3] = 1
+        K[1] = 0
+    b = ctx.register_bases(c.id, (px, py, inf)).precompute()
+    assert np.array_equal(b.msm(K), coracle.msm(c.id, (px, py, inf), K, 8))
+    if n > 10:
+        assert np.array_equal(b.msm(K[2:9], offset=2, n=7), coracle.msm(c.id, (px[2:9], py[2:9], inf[2:9]), K[2:9], 8))
+    b.free()

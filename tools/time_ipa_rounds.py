@@ -31,7 +31,10 @@ lim = lambda v: [(v >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]  # noqa: E
 X = np.tile(np.array(lim(gx * r % p), dtype=np.uint64), (2 * n + 1, 1))
 Y = np.tile(np.array(lim(gy * r % p), dtype=np.uint64), (2 * n + 1, 1))
 px, py, _ = ctx.scale_points(C, (X, Y, None), rand_field(2 * n + 1))
-bases = ctx.register_bases(C, (px[:2 * n], py[:2 * n], None))
+bases = ctx.register_bases(C, (px[:2 * n + 1], py[:2 * n + 1], None))
+use_tables = os.environ.get("BP_TABLES") == "1"
+if use_tables:
+    bases.precompute()
 u = np.concatenate([px[2 * n], py[2 * n]])
 ch = rand_field(logn)
 chi = ctx.batch_inversion(C, ch)
@@ -40,7 +43,10 @@ for c_win in cs:
     ctx.set_msm_window(c_win)
     print("window", c_win, end="  ")
     s = ctx.ipa_begin_resident(bases, 0, 0, n, rand_field(n), rand_field(n))
-    s.set_u(u)
+    if use_tables:
+        s.set_u_resident(2 * n, rand_field(1))
+    else:
+        s.set_u(u)
     t_lr, t_fold, dev = [], [], []
     for j in range(logn):
         t0 = time.perf_counter()
