@@ -180,7 +180,16 @@ def test_msm_window_sweep(ctx, coracle, c):
 def test_msm_degenerate_distributions(ctx, coracle, c):
     """range-proof A-commitment scalars ({0,1,-1}: src/range/aggregate.rs:50-64) and a
     single repeated scalar put every point of a window into one bucket"""
-    n = 8192
+    _degenerate_case(ctx, coracle, c, 8192)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_msm_degenerate_distributions_sliced_path(ctx, coracle, c):
+    """the same scalar sets at a size that takes the sliced counting sort"""
+    _degenerate_case(ctx, coracle, c, 30000)
+
+
+def _degenerate_case(ctx, coracle, c, n):
     px, py = seeded_points(coracle, c, n, 99, 101)
     rng = np.random.default_rng(8)
     bits = rng.integers(0, 2, n // 2)
@@ -191,10 +200,10 @@ def test_msm_degenerate_distributions(ctx, coracle, c):
     assert np.array_equal(ctx.msm_unchecked(c.id, (px, py, None), K2), coracle.msm(c.id, (px, py, None), K2, 8))
 
 
+@pytest.mark.parametrize("c", CURVES, ids=ids)
 @pytest.mark.parametrize("logn", [16, 18])
-def test_msm_large_closed_form(ctx, coracle, logn):
+def test_msm_large_closed_form(ctx, coracle, c, logn):
     """sum k_i (r0 + i q) G has a closed form at any size"""
-    c = o.SECP256K1
     n = 1 << logn
     r0, q = 424242, 31337
     px, py = seeded_points(coracle, c, n, r0, q)
@@ -507,8 +516,18 @@ def test_ipa_mid_size_rounds_with_u(ctx, coracle, variant):
     """n = 2^14 (the sliced counting sort with two output groups and the extra point u):
     L and R of the first rounds equal the C oracle's MSM over the folded generators plus
     c*u, and the final generators equal <s-vector, gs>, <s-vector^-1, hs>"""
+    _ipa_rounds_with_u(ctx, coracle, variant, 14, 2)
+
+
+def test_ipa_large_first_round_with_u(ctx, coracle):
+    """n = 2^17: 2^18 + 2 points in two groups take the 16-bit-window pipeline; the first
+    round's L and R equal the C oracle's MSMs plus c*u"""
+    _ipa_rounds_with_u(ctx, coracle, 0, 17, 1, full=False)
+
+
+def _ipa_rounds_with_u(ctx, coracle, variant, k, checked_rounds, full=True):
     c = o.SECP256K1
-    n, k = 1 << 14, 14
+    n = 1 << k
     gx, gy = seeded_points(coracle, c, n, 17, 19)
     hx, hy = seeded_points(coracle, c, n, 900001, 23)
     _, A = random_scalars(c, n, 41)
@@ -520,9 +539,9 @@ def test_ipa_mid_size_rounds_with_u(ctx, coracle, variant):
     bases = ctx.register_bases(c.id, (np.concatenate([gx, hx]), np.concatenate([gy, hy]), None))
     s = ctx.ipa_begin_resident(bases, variant, 0, n, A, B)
     s.set_u(np.concatenate([ux[0], uy[0]]))
-    for j in range(k):
+    for j in range(k if full else checked_rounds):
         L, R, cl, cr = s.round_lr()
-        if j < 2:
+        if j < checked_rounds:
             (g2, h2, a_cur, b_cur) = s.read() if j else ((gx, gy, None), (hx, hy, None), A, B)
             m = len(a_cur) // 2
             if variant == 0:
@@ -540,6 +559,10 @@ def test_ipa_mid_size_rounds_with_u(ctx, coracle, variant):
             eR = o.add(xyz_to_affine(coracle.msm(c.id, rb, rs, 8), c), o.scalar_mul(o.unpack_field(ecr, c.n)[0], u, c), c)
             assert xyz_to_affine(L, c) == eL and xyz_to_affine(R, c) == eR, j
         s.round_fold(CH[j:j + 1], CHI[j:j + 1])
+    if not full:
+        s.free()
+        bases.free()
+        return
     G, H, Af, Bf = s.read()
     ss = ctx.s_vector(c.id, CH, CHI)
     eg = xyz_to_affine(coracle.msm(c.id, (gx, gy, None), ss, 8), c)
