@@ -812,6 +812,8 @@ __global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ pack
 // Buckets with 0 chunks become the identity, with 2..kFinishSerial chunks are
 // summed by one lane, with more are queued for k_bucket_heavy.
 constexpr u32 kFinishSerial = 8;
+// queued buckets with up to this many chunks get one wave each, larger ones a block each
+constexpr u32 kHeavyWaveMax = 1024;
 
 template <class C>
 __global__ __launch_bounds__(128) void k_bucket_finish(const u32* __restrict__ nch,
@@ -852,6 +854,7 @@ __global__ __launch_bounds__(256) void k_bucket_heavy(const u32* __restrict__ nc
   for (u32 q = blockIdx.x; q < count; q += gridDim.x) {
     u32 b = heavy[q];
     u32 n = nch[b], off = choff[b];
+    if (n <= kHeavyWaveMax) continue;  // k_bucket_heavy_wave's share (uniform over the block)
     Xyzz acc = xyzz_identity<F>();
     for (u32 k = threadIdx.x; k < n; k += blockDim.x) {
       Xyzz v = xyzz_load_soa(chunk_sums, nc_cap, off + k);
@@ -890,6 +893,46 @@ BP_DEV Xyzz xyzz_shfl_down(const Xyzz& p, int delta, int width) {
   return r;
 }
 
+// one wave per queued bucket of moderate size (grid-stride over the queue): when a whole
+// window is crowded (a top window that the scalar field only partly fills) thousands of
+// buckets are queued, far too many for a block each
+template <class C>
+__global__ __launch_bounds__(256) void k_bucket_heavy_wave(const u32* __restrict__ nch,
+                                                           const u32* __restrict__ choff, size_t nbt,
+                                                           size_t nc_cap, const u32* __restrict__ chunk_sums,
+                                                           u32* __restrict__ buckets,
+                                                           const u32* __restrict__ heavy,
+                                                           const u32* __restrict__ heavy_count) {
+  using F = typename C::Fq;
+  const u32 count = *heavy_count;
+  const u32 lane = threadIdx.x & 63;
+  const u32 waves = gridDim.x * (blockDim.x >> 6);
+  for (u32 q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q < count; q += waves) {
+    const u32 b = heavy[q];
+    const u32 n = nch[b], off = choff[b];
+    if (n > kHeavyWaveMax) continue;  // uniform over the wave
+    Xyzz acc = xyzz_identity<F>();
+    for (u32 k = lane; k < n; k += 64) {
+      Xyzz v = xyzz_load_soa(chunk_sums, nc_cap, off + k);
+      xyzz_add<F>(acc, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      Xyzz other = xyzz_shfl_down(acc, o, 64);
+      if ((int)lane < o) xyzz_add<F>(acc, other);
+    }
+    if (lane == 0) xyzz_store_soa(buckets, nbt, b, acc);
+  }
+}
+
+// The first kTreeHeavyBlocks blocks of the launch take the crowded buckets (more than
+// `heavy_from` entries, up to kTreeHeavyMax) a whole block at a time, while the other blocks
+// run the lane groups: block h looks at buckets h, h + kTreeHeavyBlocks, ... so a crowded
+// window is spread over all of them.  Buckets beyond kTreeHeavyMax are queued for
+// k_bucket_heavy_entries.
+constexpr u32 kTreeHeavyBlocks = 128;
+constexpr u32 kTreeHeavyMax = 8192;
+constexpr u32 kTreeHeavyList = 128;  // buckets a block looks at with the default windows: <= 58 * 256 / 128
+
 template <class C>
 __global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ packed, const u32* __restrict__ vals,
                                                      const u32* __restrict__ start, const u32* __restrict__ end,
@@ -897,7 +940,57 @@ __global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ pac
                                                      u32* __restrict__ buckets, u32* __restrict__ heavy,
                                                      u32* __restrict__ heavy_count) {
   using F = typename C::Fq;
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x < kTreeHeavyBlocks) {
+    __shared__ u32 list[kTreeHeavyList];
+    __shared__ u32 n_list;
+    __shared__ u32 wave_sum[4 * 32];
+    if (threadIdx.x == 0) n_list = 0;
+    __syncthreads();
+    for (size_t b = blockIdx.x + (size_t)kTreeHeavyBlocks * threadIdx.x; b < nbt;
+         b += (size_t)kTreeHeavyBlocks * blockDim.x) {
+      const u32 cnt = end[b] - start[b];
+      if (cnt > heavy_from && cnt <= kTreeHeavyMax) {
+        const u32 slot = atomicAdd(&n_list, 1u);
+        if (slot < kTreeHeavyList)
+          list[slot] = (u32)b;
+        else  // more than the list holds (very wide windows): leave it to the queue
+          heavy[atomicAdd(heavy_count, 1u)] = (u32)b;
+      }
+    }
+    __syncthreads();
+    const u32 count = n_list < kTreeHeavyList ? n_list : kTreeHeavyList;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u32 q = 0; q < count; q++) {
+      const u32 b = list[q];
+      const u32 s = start[b], e = end[b];
+      Xyzz acc = xyzz_identity<F>();
+      for (u32 p = s + threadIdx.x; p < e; p += blockDim.x) {
+        u32 v = vals[p];
+        size_t idx = v & idx_mask;
+        Fe qx = fe_load(packed + idx * 16);
+        Fe qy = fe_load(packed + idx * 16 + 8);
+        if (v >> 31) qy = fe_neg<F>(qy);
+        xyzz_madd<F>(acc, qx, qy);
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        Xyzz o = xyzz_shfl_down(acc, off, 64);
+        if (lane < off) xyzz_add<F>(acc, o);
+      }
+      if (lane == 0) xyzz_store_aos(wave_sum + wave * 32, acc);
+      __syncthreads();
+      if (wave == 0) {
+        acc = lane < 4 ? xyzz_load_aos(wave_sum + lane * 32) : xyzz_identity<F>();
+        for (int off = 2; off > 0; off >>= 1) {
+          Xyzz o = xyzz_shfl_down(acc, off, 64);
+          if (lane < off) xyzz_add<F>(acc, o);
+        }
+        if (lane == 0) xyzz_store_soa(buckets, nbt, b, acc);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  size_t t = (size_t)(blockIdx.x - kTreeHeavyBlocks) * blockDim.x + threadIdx.x;
   size_t b = t / (size_t)lanes;
   const u32 sub = (u32)(t % (size_t)lanes);
   const bool live = b < nbt;  // whole lane groups are live or not; all lanes take part in the shuffles
@@ -908,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ pac
   }
   const bool is_heavy = e - s > heavy_from;
   if (is_heavy) {
-    if (sub == 0) heavy[atomicAdd(heavy_count, 1u)] = (u32)b;
+    if (sub == 0 && e - s > kTreeHeavyMax) heavy[atomicAdd(heavy_count, 1u)] = (u32)b;
     e = s;
   }
   Xyzz acc = xyzz_identity<F>();
@@ -1296,8 +1389,12 @@ static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspac
     while (lanes > 1 && nbt * (size_t)lanes > 65536) lanes >>= 1;
     const size_t per_bucket = plan.entries / (nbt ? nbt : 1);
     while (lanes < 64 && (size_t)lanes * 32 < per_bucket) lanes <<= 1;
-    u32 heavy_from = (u32)(16 * lanes);
-    if (heavy_from < 4 * per_bucket) heavy_from = (u32)(4 * per_bucket);
+    // a bucket with more than twice the expected entries per lane (and more than 16 per lane)
+    // would set the length of the launch's chain: it goes to a block of its own.  A scalar
+    // field well below 2^256 fills its top window this unevenly on every input.
+    size_t per_lane = 2 * ((per_bucket + (size_t)lanes - 1) / (size_t)lanes);
+    if (per_lane < 16) per_lane = 16;
+    const u32 heavy_from = (u32)(per_lane * (size_t)lanes);
     const size_t tree_threads = nbt * (size_t)lanes;
     if (nbt <= 512 && per_bucket >= 512) {
       // few buckets with many entries each (table plans on small inputs): a block per bucket
@@ -1306,7 +1403,8 @@ static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspac
                                                (const u32*)nullptr, (const u32*)nullptr));
     } else
     DISPATCH_CURVE(curve, {
-      hipLaunchKernelGGL(k_bucket_tree<C>, dim3((unsigned)((tree_threads + 255) / 256)), dim3(256), 0, st, points,
+      hipLaunchKernelGGL(k_bucket_tree<C>, dim3((unsigned)((tree_threads + 255) / 256) + kTreeHeavyBlocks), dim3(256), 0,
+                         st, points,
                          ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, lanes, heavy_from, idx_mask, ws.buckets,
                          ws.heavy, ws.heavy_count);
       hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3(256), dim3(1024), 0, st, points, ws.vals_b,
@@ -1332,6 +1430,8 @@ static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspac
       DISPATCH_CURVE(curve, {
         hipLaunchKernelGGL(k_bucket_finish<C>, dim3((unsigned)((nbt + 127) / 128)), dim3(128), 0, st, ws.nch, ws.choff,
                            nbt, plan.nc_cap, ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
+        hipLaunchKernelGGL(k_bucket_heavy_wave<C>, dim3(1024), dim3(256), 0, st, ws.nch, ws.choff, nbt, plan.nc_cap,
+                           ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
         hipLaunchKernelGGL(k_bucket_heavy<C>, dim3(256), dim3(256), 0, st, ws.nch, ws.choff, nbt, plan.nc_cap,
                            ws.chunk_sums, ws.buckets, ws.heavy, ws.heavy_count);
       });

@@ -201,6 +201,24 @@ def _degenerate_case(ctx, coracle, c, n):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("n", [12000, 40000, 1 << 19])
+def test_msm_crowded_top_window(ctx, coracle, c, n):
+    """scalars below 2^250 leave the top window a handful of buckets that hold every point:
+    crowded buckets of each size class (block within the launch, queued block, one wave per
+    bucket on the chunked path) against the closed form"""
+    r0, q = 777, 4242
+    px, py = seeded_points(coracle, c, n, r0, q)
+    rng = np.random.default_rng(n)
+    limbs = rng.integers(0, 1 << 64, (n, 4), dtype=np.uint64)
+    limbs[:, 3] &= np.uint64((1 << 58) - 1)
+    ints = [int(a) | int(b) << 64 | int(cc) << 128 | int(d) << 192 for a, b, cc, d in limbs]
+    K = o.pack_field(ints, c.n)
+    w = np.arange(n, dtype=object) * q + r0
+    exp = o.scalar_mul(int(np.dot(np.array(ints, dtype=object), w)) % c.n, c.g, c)
+    assert xyz_to_affine(ctx.msm_unchecked(c.id, (px, py, None), K), c) == exp
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
 @pytest.mark.parametrize("logn", [16, 18])
 def test_msm_large_closed_form(ctx, coracle, c, logn):
     """sum k_i (r0 + i q) G has a closed form at any size"""

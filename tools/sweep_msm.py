@@ -15,7 +15,7 @@ import bulletproofs_amd as bp  # noqa: E402
 sys.argv = sys.argv[:1] + [a for a in sys.argv[1:]]
 logs = [int(a) for a in sys.argv[1:]] or [16, 17, 18, 19, 20]
 ctx = bp.Context(0)
-C = bp.SECP256K1
+C = bp.VESTA if os.environ.get("CURVE") == "vesta" else bp.SECP256K1
 rng = np.random.default_rng(7)
 
 
@@ -25,7 +25,7 @@ def dev(a):
 
 def rand_field(n):
     a = rng.integers(0, 1 << 64, (n, 4), dtype=np.uint64)
-    a[:, 3] &= np.uint64((1 << 63) - 1)
+    a[:, 3] &= np.uint64((1 << (61 if C == bp.VESTA else 63)) - 1)
     return a
 
 
@@ -34,6 +34,10 @@ def gen_points(n):
     order = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
     gx = 0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798
     gy = 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8
+    if C == bp.VESTA:
+        p = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+        order = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+        gx, gy = p - 1, 2
     r = 1 << 256
     lim = lambda v: [(v >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]  # noqa: E731
     X = np.tile(np.array(lim(gx * r % p), dtype=np.uint64), (n, 1))
