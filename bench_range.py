@@ -6,8 +6,6 @@ import json
 import os
 import sys
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import bulletproofs_amd as bp  # noqa: E402
@@ -18,25 +16,7 @@ m = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n_bits = 64
 n = m * n_bits
 ctx = bp.Context(0)
-p = (1 << 256) - (1 << 32) - 977
-order = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
-gx = 0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798
-gy = 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8
-r = 1 << 256
-lim = lambda v: [(v >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]  # noqa: E731
-cnt = 2 * n + 3
-X = np.tile(np.array(lim(gx * r % p), dtype=np.uint64), (cnt, 1))
-Y = np.tile(np.array(lim(gy * r % p), dtype=np.uint64), (cnt, 1))
-rng = np.random.default_rng(SEED)
-S = rng.integers(0, 1 << 64, (cnt, 4), dtype=np.uint64)
-S[:, 3] &= np.uint64((1 << 63) - 1)
-px, py, _ = ctx.scale_points(bp.SECP256K1, (X, Y, None), S)  # CRS: random multiples of G
-gs = (px[:n], py[:n], None)
-hs = (px[n:2 * n], py[n:2 * n], None)
-ugh = np.concatenate([px[2 * n:], py[2 * n:]], axis=1)
-values = rng.integers(0, 1 << 64, m, dtype=np.uint64)
-gamma = rng.integers(0, 1 << 64, (m, 4), dtype=np.uint64)
-gamma[:, 3] &= np.uint64((1 << 63) - 1)
+gs, hs, ugh, values, gamma = host_mirror.range_bench_inputs(ctx, m, n_bits, SEED)
 host_mirror.range_aggregate_roundtrip(ctx, bp.SECP256K1, gs, hs, ugh, values, gamma, n_bits, SEED, SEED + 1, reps=1)
 res = host_mirror.range_aggregate_roundtrip(ctx, bp.SECP256K1, gs, hs, ugh, values, gamma, n_bits, SEED, SEED + 1, reps=5)
 assert res["ok"]

@@ -146,3 +146,31 @@ def poly_commit_roundtrip(ctx: Context, curve, gs, h_gen_xy, coeffs, r, x, seed_
         raise RuntimeError(f"bph_poly_roundtrip rc={rc}")
     return dict(L=L[:k], R=R[:k], a=ar[0], r=ar[1], g=g, commitment=com, evaluation=ev, prove_ms=tp.value,
                 verify_ms=tv.value, verify_ok=bool(okv.value), lazy_ok=bool(okl.value), halo_ok=bool(okh.value))
+
+
+def range_bench_inputs(ctx: Context, m, n_bits, seed):
+    """Synthetic inputs of the aggregated range proof bench (benches/aggregate_range_bench.rs:30-52):
+    a CRS of 2*m*n_bits + 3 random multiples of the secp256k1 generator (gs, hs, then u, g, h),
+    m uniform n_bits-bit values and their blinding factors, all from one numpy seed."""
+    from .api import SECP256K1
+    n = m * n_bits
+    p = (1 << 256) - (1 << 32) - 977
+    gx = 0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798
+    gy = 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8
+    r = 1 << 256
+    lim = lambda v: [(v >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]  # noqa: E731
+    cnt = 2 * n + 3
+    X = np.tile(np.array(lim(gx * r % p), dtype=np.uint64), (cnt, 1))
+    Y = np.tile(np.array(lim(gy * r % p), dtype=np.uint64), (cnt, 1))
+    rng = np.random.default_rng(seed)
+    S = rng.integers(0, 1 << 64, (cnt, 4), dtype=np.uint64)
+    S[:, 3] &= np.uint64((1 << 63) - 1)
+    px, py, _ = ctx.scale_points(SECP256K1, (X, Y, None), S)
+    gs = (px[:n], py[:n], None)
+    hs = (px[n:2 * n], py[n:2 * n], None)
+    ugh = np.concatenate([px[2 * n:], py[2 * n:]], axis=1)
+    hi = (1 << n_bits) if n_bits < 64 else (1 << 64)
+    values = rng.integers(0, hi, m, dtype=np.uint64)
+    gamma = rng.integers(0, 1 << 64, (m, 4), dtype=np.uint64)
+    gamma[:, 3] &= np.uint64((1 << 63) - 1)
+    return gs, hs, ugh, values, gamma
