@@ -42,6 +42,8 @@ struct bp_ctx {
   float last_ms[3] = {0, 0, 0};
   void* ipa_cache = nullptr;  // device block of the last freed IPA session, reused by the next
   size_t ipa_cache_bytes = 0;
+  MsmPipe pipe;         // second and third stream of large MSMs
+  int last_stages = 1;  // batches of the last MSM (its accumulation time is the sum over pipe.cs0/cs1)
 };
 
 struct bp_bases {
@@ -196,7 +198,7 @@ void finish_windows(int curve, const uint64_t* win, int n_windows, int c, uint64
 int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, MsmPlan* plan,
                u32** d_windows, int groups = 1, const MsmExtra* extra = nullptr, const MsmTable* table = nullptr) {
   size_t n = p0.n + p1.n + (extra ? 2 : 0);
-  hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan, table ? table->stride : 0);
+  hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan, table ? table->stride : 0, true);
   if (e != hipSuccess) return fail(ctx, BP_E_ARG, "msm plan (n too large?)", e);
   MsmWorkspace ws{};
   void* p;
@@ -225,7 +227,8 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
   CHK(reserve(ctx, S_SEG_GROUPS, plan->seg_group_bytes, &p)); ws.seg_groups = (u32*)p;
   CHK(reserve(ctx, S_WINDOWS, plan->win_bytes, &p)); ws.windows = (u32*)p;
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  e = msm_run(curve, p0, p1, extra, *plan, ws, ctx->stream, ctx->ev[2], ctx->ev[3], table);
+  ctx->last_stages = plan->stages;
+  e = msm_run(curve, p0, p1, extra, *plan, ws, ctx->stream, ctx->ev[2], ctx->ev[3], table, &ctx->pipe);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "msm_run", e);
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   *d_windows = ws.windows;
@@ -235,7 +238,15 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
 void msm_collect_times(bp_ctx* ctx, bool had_points) {
   float ms = 0;
   if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_ms[1] = ms;
-  if (had_points && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[0] = ms;
+  if (!had_points) return;
+  if (ctx->last_stages <= 1) {
+    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[0] = ms;
+    return;
+  }
+  float total = 0;
+  for (int g = 0; g < ctx->last_stages; g++)
+    if (hipEventElapsedTime(&ms, ctx->pipe.cs0[g], ctx->pipe.cs1[g]) == hipSuccess) total += ms;
+  ctx->last_ms[0] = total;
 }
 
 int msm_full(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, uint64_t out_xyz[12],
@@ -293,6 +304,21 @@ int bp_init(int device, bp_ctx** out) {
       return BP_E_HIP;
     }
   }
+  {
+    MsmPipe& p = c->pipe;
+    bool ok = hipStreamCreateWithFlags(&p.front, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&p.reduce, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&p.start, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&p.done, hipEventDisableTiming) == hipSuccess;
+    for (int g = 0; ok && g < kMsmMaxStages; g++)
+      ok = hipEventCreateWithFlags(&p.sorted[g], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&p.summed[g], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreate(&p.cs0[g]) == hipSuccess && hipEventCreate(&p.cs1[g]) == hipSuccess;
+    if (!ok) {
+      bp_shutdown(c);
+      return BP_E_HIP;
+    }
+  }
   *out = c;
   return BP_OK;
 }
@@ -307,6 +333,19 @@ void bp_shutdown(bp_ctx* ctx) {
   if (ctx->ipa_cache) (void)hipFree(ctx->ipa_cache);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
+  {
+    MsmPipe& p = ctx->pipe;
+    hipEvent_t singles[2] = {p.start, p.done};
+    for (hipEvent_t e : singles)
+      if (e) (void)hipEventDestroy(e);
+    for (int g = 0; g < kMsmMaxStages; g++) {
+      hipEvent_t evs[4] = {p.sorted[g], p.summed[g], p.cs0[g], p.cs1[g]};
+      for (hipEvent_t e : evs)
+        if (e) (void)hipEventDestroy(e);
+    }
+    if (p.front) (void)hipStreamDestroy(p.front);
+    if (p.reduce) (void)hipStreamDestroy(p.reduce);
+  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

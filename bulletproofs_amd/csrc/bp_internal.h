@@ -120,10 +120,24 @@ struct MsmPlan {
   bool mid;       // sliced counting sort (three launches), tree accumulation
   bool tab;       // points come from window tables: all digit windows share one bucket set per group
   int digit_windows;  // windows of the digit decomposition (= group_windows unless tab)
+  int stages;     // > 1: the windows are processed in this many consecutive batches on three streams
+};
+
+// Large single-sum plans run their windows in batches: sorting and the chunk table of batch
+// g+1 (memory-bound) and the bucket reduction of batch g-1 (a long dependent chain on few
+// lanes) overlap the accumulation of batch g (multiplier-bound).  Streams and events are owned
+// by the caller; cs0/cs1 bracket each batch's accumulation kernel.
+constexpr int kMsmMaxStages = 8;
+struct MsmPipe {
+  hipStream_t front = nullptr, reduce = nullptr;
+  hipEvent_t start = nullptr, done = nullptr;
+  hipEvent_t sorted[kMsmMaxStages] = {}, summed[kMsmMaxStages] = {};
+  hipEvent_t cs0[kMsmMaxStages] = {}, cs1[kMsmMaxStages] = {};
 };
 
 int msm_choose_window(size_t n);
-hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride = 0);
+hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride = 0,
+                         bool allow_stages = false);
 
 struct MsmWorkspace {
   u32* packed;        // points as x|y pairs, 16 u32 each
@@ -163,7 +177,7 @@ struct MsmExtra {
 // accumulation kernel.
 hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExtra* extra, const MsmPlan& plan,
                    const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1,
-                   const MsmTable* table = nullptr);
+                   const MsmTable* table = nullptr, const MsmPipe* pipe = nullptr);
 // sums n_parts arrays of n_windows XYZZ points window by window into out (n_windows XYZZ)
 hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int n_windows, u32* out,
                                  hipStream_t st);

@@ -78,7 +78,8 @@ static int key_bits_for(u32 max_key) {
   return b;
 }
 
-hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride) {
+hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride,
+                         bool allow_stages) {
   MsmPlan p{};
   if (groups < 1 || groups > 2) return hipErrorInvalidValue;
   p.groups = groups;
@@ -108,14 +109,33 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   // Buckets per reduction lane: the reduction is a dependent chain of 2*seg_len additions
   // plus a multiplication by the segment offset, so short segments win as long as the
   // lanes still fit the machine about once (256 CUs * 4 SIMDs * 64 lanes).
+  // Batches of windows for the three-stream pipeline (single sums on the chunked path): off
+  // unless BP_MSM_STAGES asks for it.  Measured on MI355X at 2^20 points it loses (2.38 ms in
+  // one batch, 2.90 in two, 3.40 in four): the streams do overlap, but every batch pays the
+  // launch-bound part of the front end again (the chunk-length sort of a quarter of the chunks
+  // is a merge sort of some forty launches) and its reduction is the same dependent chain
+  // whatever the number of windows, slower still while the accumulation shares the SIMDs.
+  p.stages = 1;
+  {
+    const bool chunked = !(small_ok && p.n_buckets <= kSmallMaxBuckets) && !p.tab &&
+                         !(p.n_buckets >= 64 && p.n_buckets <= kMidMaxBuckets && n_total <= ((size_t)1 << 20));
+    int want = 1;
+    if (const char* ev = getenv("BP_MSM_STAGES")) want = atoi(ev);
+    if (allow_stages && chunked && groups == 1 && want > 1) {
+      if (want > kMsmMaxStages) want = kMsmMaxStages;
+      if (want > p.n_windows) want = p.n_windows;
+      p.stages = want;
+    }
+  }
+  const int stage_windows = (p.n_windows + p.stages - 1) / p.stages;  // windows reduced by one launch
   p.seg_len = 16;
-  while (p.seg_len > 4 && (size_t)p.n_windows * p.n_buckets / (p.seg_len / 2) <= 65536) p.seg_len /= 2;
+  while (p.seg_len > 4 && (size_t)stage_windows * p.n_buckets / (p.seg_len / 2) <= 65536) p.seg_len /= 2;
   if (const char* ev = getenv("BP_MSM_SEG_LEN")) p.seg_len = atoi(ev);
   if ((u32)p.seg_len > p.n_buckets) p.seg_len = (int)p.n_buckets;
   p.n_segs = p.n_buckets / p.seg_len;
   size_t nbt = (size_t)p.n_windows * p.n_buckets;
   p.keys_bytes = ((p.entries * sizeof(u32)) + 255) & ~(size_t)255;
-  p.bounds_bytes = ((nbt + 2) * sizeof(u32) + 255) & ~(size_t)255;
+  p.bounds_bytes = ((nbt + 2 + kMsmMaxStages) * sizeof(u32) + 255) & ~(size_t)255;
   p.bucket_bytes = nbt * 4 * 32;
   p.seg_bytes = (size_t)p.n_windows * p.n_segs * 128;
   p.seg_group_bytes = (size_t)p.n_windows * (p.n_segs / 1024 + 1) * 128;
@@ -151,7 +171,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   // very large inputs: about 2^21 chunks are plenty of lanes, and longer chunks keep the
   // number of partial sums per bucket small
   if ((p.entries >> 21) > p.chunk) p.chunk = (u32)((p.entries >> 21) > 4096 ? 4096 : (p.entries >> 21));
-  p.nc_cap = p.entries / p.chunk + nbt + 1;
+  p.nc_cap = p.entries / p.chunk + nbt + 1 + kMsmMaxStages;  // room for one rounding slot per batch
   p.small = small_ok && p.n_buckets <= kSmallMaxBuckets && !p.tab;
   // narrow windows on more points than one block sorts: the sliced counting sort
   p.mid = p.tab || (!p.small && n_total > 0 && p.n_buckets >= 64 && p.n_buckets <= kMidMaxBuckets &&
@@ -162,7 +182,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
     size_t need = (size_t)p.n_windows * (p.tab ? p.entries : n_total) * sizeof(u32);
     if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
   }
-  p.nch_bytes = ((nbt + 2) * sizeof(u32) + 255) & ~(size_t)255;
+  p.nch_bytes = ((nbt + 2 + kMsmMaxStages) * sizeof(u32) + 255) & ~(size_t)255;
   p.chunk_sum_bytes = p.nc_cap * 4 * 32;
   tmp = 0;
   e = rocprim::exclusive_scan(nullptr, tmp, (u32*)nullptr, (u32*)nullptr, 0u, nbt + 1, rocprim::plus<u32>(), 0, false);
@@ -681,7 +701,7 @@ __global__ __launch_bounds__(1024) void k_mid_scatter(const u32* __restrict__ tm
 
 // ---- 3. bucket bounds ---------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ keys, const u32* __restrict__ vals,
-                                                size_t entries, u32 n_buckets, int wshift,
+                                                size_t entries, u32 n_buckets, int wshift, u32 window_base,
                                                 u32* __restrict__ start, u32* __restrict__ end) {
   // The sort key is the bucket number alone; the input was window-major and the sort
   // is stable, so equal keys stay in window order: runs of equal (bucket, window) are
@@ -692,7 +712,7 @@ __global__ __launch_bounds__(256) void k_bounds(const u32* __restrict__ keys, co
   if (k >= n_buckets) return;  // zero digit / identity base
   const u32 wmask = 0x7fffffffu >> wshift << wshift;
   u32 w = vals[p] & wmask;
-  u32 b = (w >> wshift) * n_buckets + k;
+  u32 b = ((w >> wshift) - window_base) * n_buckets + k;
   if (p == 0 || keys[p - 1] != k || (vals[p - 1] & wmask) != w) start[b] = (u32)p;
   if (p + 1 == entries || keys[p + 1] != k || (vals[p + 1] & wmask) != w) end[b] = (u32)(p + 1);
 }
@@ -1279,12 +1299,15 @@ hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int
 
 static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st,
                                hipEvent_t ev_acc0, hipEvent_t ev_acc1, const u32* table_rec = nullptr);
+static hipError_t msm_sort_and_chunk(const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st, u32 window_base);
+static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st,
+                                 hipEvent_t ev_acc0, hipEvent_t ev_acc1, const u32* table_rec);
+static hipError_t msm_reduce(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st);
 
 hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExtra* extra, const MsmPlan& plan,
                    const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1,
-                   const MsmTable* table) {
+                   const MsmTable* table, const MsmPipe* pipe) {
   const size_t n = plan.n_total;
-  const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
   hipError_t e;
   if (n == 0) {
     // all windows = identity (zz = 0)
@@ -1347,6 +1370,68 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
                                            plan.group_windows, plan.n_buckets, plan.wshift, ws.keys_a, ws.vals_a, p0.x, p0.y, p1.x, p1.y,
                                            ws.packed, sel));
   if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (plan.stages <= 1) {
+    if ((e = msm_sort_and_chunk(plan, ws, st, 0)) != hipSuccess) return e;
+    return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
+  }
+  // batches of windows on three streams (see MsmPipe)
+  if (!pipe || !pipe->front || !pipe->reduce) return hipErrorInvalidValue;
+  if ((e = hipEventRecord(pipe->start, st)) != hipSuccess) return e;
+  if ((e = hipStreamWaitEvent(pipe->front, pipe->start, 0)) != hipSuccess) return e;
+  if ((e = hipStreamWaitEvent(pipe->reduce, pipe->start, 0)) != hipSuccess) return e;
+  const int per = (plan.n_windows + plan.stages - 1) / plan.stages;
+  size_t chunk_base = 0;
+  for (int g = 0, w0 = 0; w0 < plan.n_windows; g++, w0 += per) {
+    const int wn = plan.n_windows - w0 < per ? plan.n_windows - w0 : per;
+    // the batch as a plan and a workspace of its own: windows [w0, w0 + wn)
+    MsmPlan sub = plan;
+    sub.stages = 1;
+    sub.n_windows = sub.group_windows = sub.digit_windows = wn;
+    sub.entries = (size_t)wn * n;
+    const size_t nb = (size_t)wn * plan.n_buckets, b0 = (size_t)w0 * plan.n_buckets;
+    sub.nc_cap = sub.entries / plan.chunk + nb + 1;
+    sub.bounds_bytes = (nb + 1) * sizeof(u32);
+    MsmWorkspace wg = ws;
+    wg.keys_a += (size_t)w0 * n;
+    wg.keys_b += (size_t)w0 * n;
+    wg.vals_a += (size_t)w0 * n;
+    wg.vals_b += (size_t)w0 * n;
+    wg.bucket_start += b0 + g;
+    wg.bucket_end += b0 + g;
+    wg.nch += b0 + g;
+    wg.choff += b0 + g;
+    wg.heavy += b0;
+    wg.heavy_count += g;
+    wg.buckets += b0 * 32;
+    wg.chunk_sums += chunk_base * 32;
+    wg.ckey_a += chunk_base;
+    wg.ckey_b += chunk_base;
+    wg.cval_a += chunk_base;
+    wg.cval_b += chunk_base;
+    wg.desc_b += chunk_base;
+    wg.desc_s += chunk_base;
+    wg.segs += (size_t)w0 * plan.n_segs * 32;
+    wg.seg_groups += (size_t)w0 * (plan.n_segs / 1024 + 1) * 32;
+    wg.windows += (size_t)w0 * 32;
+    chunk_base += sub.nc_cap;
+    if (chunk_base > plan.nc_cap) return hipErrorInvalidValue;
+    if ((e = msm_sort_and_chunk(sub, wg, pipe->front, (u32)w0)) != hipSuccess) return e;
+    if ((e = hipEventRecord(pipe->sorted[g], pipe->front)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(st, pipe->sorted[g], 0)) != hipSuccess) return e;
+    if ((e = msm_accumulate(curve, sub, wg, st, pipe->cs0[g], pipe->cs1[g], nullptr)) != hipSuccess) return e;
+    if ((e = hipEventRecord(pipe->summed[g], st)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(pipe->reduce, pipe->summed[g], 0)) != hipSuccess) return e;
+    if ((e = msm_reduce(curve, sub, wg, pipe->reduce)) != hipSuccess) return e;
+  }
+  if ((e = hipEventRecord(pipe->done, pipe->reduce)) != hipSuccess) return e;
+  return hipStreamWaitEvent(st, pipe->done, 0);
+}
+
+// chunked path, after the digits: radix sort of (bucket, entry) pairs, bucket bounds, chunk table
+// sorted by chunk length.  window_base = number of the first window of the entries given.
+static hipError_t msm_sort_and_chunk(const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st, u32 window_base) {
+  const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
+  hipError_t e;
   size_t tmp = plan.sort_tmp_bytes;
   e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
       ws.sort_tmp, tmp, ws.keys_a, ws.keys_b, ws.vals_a, ws.vals_b, plan.entries, 0,
@@ -1355,7 +1440,7 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
   if ((e = hipMemsetAsync(ws.bucket_start, 0, plan.bounds_bytes, st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(ws.bucket_end, 0, plan.bounds_bytes, st)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_bounds, dim3((unsigned)((plan.entries + 255) / 256)), dim3(256), 0, st, ws.keys_b,
-                     ws.vals_b, plan.entries, plan.n_buckets, plan.wshift, ws.bucket_start, ws.bucket_end);
+                     ws.vals_b, plan.entries, plan.n_buckets, plan.wshift, window_base, ws.bucket_start, ws.bucket_end);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   hipLaunchKernelGGL(k_chunk_counts, dim3((unsigned)((nbt + 256) / 256)), dim3(256), 0, st, ws.bucket_start,
                      ws.bucket_end, nbt, plan.chunk, ws.nch);
@@ -1368,15 +1453,20 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
                      ws.bucket_end, ws.choff, nbt, plan.chunk, plan.nc_cap, ws.ckey_a, ws.cval_a, ws.desc_b, ws.desc_s);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   tmp = plan.csort_tmp_bytes;
-  e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
+  return rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
       ws.csort_tmp, tmp, ws.ckey_a, ws.ckey_b, ws.cval_a, ws.cval_b, plan.nc_cap, 0, kChunkKeyBits, st, false);
-  if (e != hipSuccess) return e;
-  return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
 }
 
 // accumulation and reduction over a finished entry order and chunk table
 static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st,
                                hipEvent_t ev_acc0, hipEvent_t ev_acc1, const u32* table_rec) {
+  hipError_t e = msm_accumulate(curve, plan, ws, st, ev_acc0, ev_acc1, table_rec);
+  return e != hipSuccess ? e : msm_reduce(curve, plan, ws, st);
+}
+
+// bucket sums from the sorted entries
+static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st,
+                                 hipEvent_t ev_acc0, hipEvent_t ev_acc1, const u32* table_rec) {
   const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
   const u32* points = table_rec ? table_rec : ws.packed;  // 64-byte x|y records the entries index
   hipError_t e;
@@ -1438,6 +1528,12 @@ static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspac
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
+  return hipSuccess;
+}
+
+// window sums from the bucket sums
+static hipError_t msm_reduce(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st) {
+  const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
   if (plan.n_buckets >= 64 && plan.n_buckets <= 256) {
     int log_nb = 0;
     while ((1u << log_nb) < plan.n_buckets) log_nb++;

@@ -218,6 +218,21 @@ def test_msm_crowded_top_window(ctx, coracle, c, n):
     assert xyz_to_affine(ctx.msm_unchecked(c.id, (px, py, None), K), c) == exp
 
 
+@pytest.mark.parametrize("stages", [2, 3, 8])
+def test_msm_window_batches(ctx, coracle, stages, monkeypatch):
+    """BP_MSM_STAGES runs the windows of a large MSM in batches on three streams; same sum"""
+    c = o.SECP256K1
+    n = 1 << 18
+    r0, q = 5150, 2112
+    px, py = seeded_points(coracle, c, n, r0, q)
+    ints, K = random_scalars(c, n, 77)
+    w = np.arange(n, dtype=object) * q + r0
+    exp = o.scalar_mul(int(np.dot(np.array(ints, dtype=object), w)) % c.n, c.g, c)
+    monkeypatch.setenv("BP_MSM_STAGES", str(stages))
+    for _ in range(2):  # twice: the second call reuses streams, events and workspace
+        assert xyz_to_affine(ctx.msm_unchecked(c.id, (px, py, None), K), c) == exp
+
+
 @pytest.mark.parametrize("c", CURVES, ids=ids)
 @pytest.mark.parametrize("logn", [16, 18])
 def test_msm_large_closed_form(ctx, coracle, c, logn):
