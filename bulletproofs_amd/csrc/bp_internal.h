@@ -121,6 +121,7 @@ struct MsmPlan {
   bool tab;       // points come from window tables: all digit windows share one bucket set per group
   int digit_windows;  // windows of the digit decomposition (= group_windows unless tab)
   int stages;     // > 1: the windows are processed in this many consecutive batches on three streams
+  bool two_level; // chunked path: two-level counting sort in place of the key-value radix sort
 };
 
 // Large single-sum plans run their windows in batches: sorting and the chunk table of batch

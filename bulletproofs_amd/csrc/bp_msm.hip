@@ -55,6 +55,9 @@ constexpr u32 kSmallMaxBuckets = 4096;
 constexpr int kMidIters = 8;
 constexpr u32 kMidSlice = kSmallThreads * kMidIters;
 constexpr u32 kMidMaxBuckets = 256;
+constexpr int kTwoLevelLoBits = 8;       // see the two-level counting sort
+constexpr u32 kTwoLevelMaxBins = 2048;
+constexpr int kTwoLevelIdxBits = 22;
 
 static inline int ilog2_floor(size_t n) {
   int l = 0;
@@ -182,6 +185,12 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
     size_t need = (size_t)p.n_windows * (p.tab ? p.entries : n_total) * sizeof(u32);
     if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
   }
+  // single sums on the chunked path sort with the two-level counting sort when the bucket
+  // number has a high part and the counters of all (window, partition) pairs fit one block
+  p.two_level = !p.small && !p.mid && !p.tab && groups == 1 && p.stages == 1 && n_total > 0 &&
+                n_total <= ((size_t)1 << kTwoLevelIdxBits) && p.n_buckets >= (2u << kTwoLevelLoBits) &&
+                (size_t)p.n_windows * (p.n_buckets >> kTwoLevelLoBits) <= kTwoLevelMaxBins &&
+                nbt + 2 >= 2 * (size_t)kTwoLevelMaxBins && !getenv("BP_MSM_RADIX");
   p.nch_bytes = ((nbt + 2 + kMsmMaxStages) * sizeof(u32) + 255) & ~(size_t)255;
   p.chunk_sum_bytes = p.nc_cap * 4 * 32;
   tmp = 0;
@@ -696,6 +705,255 @@ __global__ __launch_bounds__(1024) void k_mid_scatter(const u32* __restrict__ tm
       idx = (size_t)w * tab_stride + base_index;
     }
     sorted_vals[pos] = (u32)idx | (wid << wshift) | sign;
+  }
+}
+
+// ---- 1-3 for large single sums: two-level counting sort -----------------------------------
+// The bucket number splits into a high part (the partition) and kTwoLoBits low bits.
+// k_two_digits writes every point's digits once (16 bits each) and counts the entries of each
+// (window, partition); k_two_scatter moves a word (point index | low bits | sign) per entry
+// into its partition, reserving room for a block's share of a partition with one global
+// atomic; k_two_sort_lo finishes each partition in LDS (one block each) and writes the sorted
+// entries and the bucket bounds.  Three passes over 2-4 bytes per entry instead of the
+// key-value radix sort's passes over 8 and a bounds pass.  The order of entries inside a bucket is arbitrary, the bucket sums are not.
+constexpr int kTwoLoBits = kTwoLevelLoBits;
+constexpr u32 kTwoLo = 1u << kTwoLoBits;
+constexpr u32 kTwoMaxBins = kTwoLevelMaxBins;  // windows * partitions per window, counters of one block
+constexpr int kTwoIdxBits = kTwoLevelIdxBits;  // point index inside a word; low bucket bits sit above it
+constexpr u32 kTwoDigitPoints = 2048;   // points per block of k_two_digits
+constexpr u32 kTwoScatterPoints = 4096; // points per block of k_two_scatter
+constexpr int kTwoIters = 15;        // entries per lane that k_two_sort_lo keeps (registers, then 60 KB of LDS)
+constexpr uint16_t kTwoNoDigit = 0xffffu;  // (bucket 2^15 - 1, negative digit) cannot occur
+
+// Rank of this lane's entry in the LDS counter hist[key]; every lane of the wave must call.
+// When all valid lanes hold the same key (crowded buckets, degenerate scalar sets) the wave
+// adds once instead of serialising 64 atomics on one address.
+__device__ __forceinline__ u32 lds_rank(u32* hist, u32 key, bool valid) {
+  const unsigned long long m = __ballot(valid);
+  if (m == 0) return 0;
+  const int leader = __ffsll((long long)m) - 1;
+  const u32 k0 = (u32)__shfl((int)key, leader, 64);
+  if (__all(!valid || key == k0)) {
+    u32 base = 0;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&hist[k0], (u32)__popcll(m));
+    base = (u32)__shfl((int)base, leader, 64);
+    return base + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+  }
+  return valid ? atomicAdd(&hist[key], 1u) : 0u;
+}
+
+template <class C>
+__global__ __launch_bounds__(1024) void k_two_digits(const u32* __restrict__ s0, const uint8_t* __restrict__ inf0,
+                                                     size_t n0, const u32* __restrict__ s1,
+                                                     const uint8_t* __restrict__ inf1, size_t n1,
+                                                     const u32* __restrict__ x0, const u32* __restrict__ y0,
+                                                     const u32* __restrict__ x1, const u32* __restrict__ y1, int c,
+                                                     int n_windows, u32 n_hi, u32* __restrict__ packed,
+                                                     uint16_t* __restrict__ digits, uint8_t* __restrict__ flips,
+                                                     u32* __restrict__ part_count) {
+  using Fr = typename C::Fr;
+  __shared__ u32 hist[kTwoMaxBins];
+  const size_t n = n0 + n1;
+  const u32 bins = (u32)n_windows * n_hi;
+  for (u32 q = threadIdx.x; q < bins; q += blockDim.x) hist[q] = 0;
+  __syncthreads();
+  const u32 half = 1u << (c - 1), mask = (1u << c) - 1;
+  for (u32 it = 0; it < kTwoDigitPoints / 1024; it++) {
+    const size_t i = (size_t)blockIdx.x * kTwoDigitPoints + (size_t)it * 1024 + threadIdx.x;
+    const bool live = i < n;
+    const size_t ii = live ? i : 0;
+    const bool second = ii >= n0;
+    Fe k = fe_zero();
+    bool is_inf = true;
+    u32 flip = 0;
+    if (live) {
+      const u32* px = second ? x1 + (ii - n0) * 8 : x0 + ii * 8;
+      const u32* py = second ? y1 + (ii - n0) * 8 : y0 + ii * 8;
+      fe_store(packed + ii * 16, fe_load(px));
+      fe_store(packed + ii * 16 + 8, fe_load(py));
+      is_inf = second ? (inf1 && inf1[ii - n0]) : (inf0 && inf0[ii]);
+      k = fe_from_mont<Fr>(fe_load(second ? s1 + (ii - n0) * 8 : s0 + ii * 8));
+      // |k| <= r/2: use r - k with the point negated when that is the smaller value
+      Fe nk = fe_neg<Fr>(k);
+      bool gt = false, decided = false;
+#pragma unroll
+      for (int t = 7; t >= 0; t--) {
+        if (!decided && k.v[t] != nk.v[t]) {
+          gt = k.v[t] > nk.v[t];
+          decided = true;
+        }
+      }
+      if (gt) {
+        k = nk;
+        flip = 1;
+      }
+      flips[ii] = (uint8_t)flip;
+    }
+    u32 carry = 0;
+    for (int w = 0; w < n_windows; w++) {
+      const int bit = w * c, limb = bit >> 5, sh = bit & 31;
+      u32 raw = 0;
+      if (limb < 8) {
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+          lo = (t == limb) ? k.v[t] : lo;
+          hi = (t == limb + 1) ? k.v[t] : hi;
+        }
+        unsigned long long two = ((unsigned long long)hi << 32) | lo;
+        raw = (u32)(two >> sh) & mask;
+      }
+      const u32 v = raw + carry;
+      u32 mag, neg;
+      if (v > half) {
+        carry = 1;
+        mag = (1u << c) - v;
+        neg = 1;
+      } else {
+        carry = 0;
+        mag = v;
+        neg = 0;
+      }
+      const bool valid = live && !is_inf && mag != 0;
+      const u32 key = mag - 1;
+      if (live) digits[(size_t)w * n + ii] = valid ? (uint16_t)(key | (neg << 15)) : kTwoNoDigit;
+      lds_rank(hist, (u32)w * n_hi + (key >> kTwoLoBits), valid);
+    }
+  }
+  __syncthreads();
+  for (u32 q = threadIdx.x; q < bins; q += blockDim.x)
+    if (hist[q]) atomicAdd(&part_count[q], hist[q]);
+}
+
+// start of partition h of window w inside the window's slice of n entries; every lane of the
+// block calls (blockDim = 1024)
+__device__ __forceinline__ u32 two_partition_scan(const u32* __restrict__ part_count, u32 w, u32 n_hi, size_t n,
+                                                  u32* wave_sums) {
+  u32 total;
+  const u32 mine = threadIdx.x < n_hi ? part_count[w * n_hi + threadIdx.x] : 0u;
+  return (u32)((size_t)w * n) + block_exclusive_scan(mine, wave_sums, &total);
+}
+
+// word: point index | low bucket bits << kTwoIdxBits | sign << 31.  The block's entries are
+// ordered by partition in LDS first, so that what goes to one partition leaves as one run.
+__global__ __launch_bounds__(1024) void k_two_scatter(const uint16_t* __restrict__ digits,
+                                                      const uint8_t* __restrict__ flips,
+                                                      const u32* __restrict__ part_count, size_t n, u32 n_hi,
+                                                      u32* __restrict__ cursor, u32* __restrict__ words) {
+  __shared__ u32 hist[kTwoLo], gbase[kTwoLo], loff[kTwoLo];  // n_hi <= kTwoLo
+  __shared__ u32 st_word[kTwoScatterPoints], st_dst[kTwoScatterPoints];
+  __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
+  const u32 w = blockIdx.y;
+  if (threadIdx.x < kTwoLo) hist[threadIdx.x] = 0;
+  __syncthreads();
+  constexpr int kIters = kTwoScatterPoints / 1024;
+  u32 my_word[kIters], my_hi[kIters], my_rank[kIters];
+#pragma unroll
+  for (int it = 0; it < kIters; it++) {
+    const size_t i = (size_t)blockIdx.x * kTwoScatterPoints + (size_t)it * 1024 + threadIdx.x;
+    u32 d = kTwoNoDigit;
+    u32 flip = 0;
+    if (i < n) {
+      d = digits[(size_t)w * n + i];
+      flip = flips[i];
+    }
+    const bool valid = d != kTwoNoDigit;
+    const u32 key = d & 0x7fffu, sign = (d >> 15) ^ flip;
+    my_hi[it] = valid ? key >> kTwoLoBits : n_hi;
+    my_word[it] = (u32)i | ((key & (kTwoLo - 1)) << kTwoIdxBits) | (sign << 31);
+    my_rank[it] = lds_rank(hist, key >> kTwoLoBits, valid);
+  }
+  __syncthreads();
+  const u32 part = two_partition_scan(part_count, w, n_hi, n, wave_sums);
+  u32 total;
+  const u32 mine = threadIdx.x < n_hi ? hist[threadIdx.x] : 0u;
+  const u32 before = block_exclusive_scan(mine, wave_sums, &total);
+  if (threadIdx.x < n_hi) {
+    loff[threadIdx.x] = before;
+    gbase[threadIdx.x] = mine ? part + atomicAdd(&cursor[w * n_hi + threadIdx.x], mine) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kIters; it++)
+    if (my_hi[it] < n_hi) {
+      const u32 j = loff[my_hi[it]] + my_rank[it];
+      st_word[j] = my_word[it];
+      st_dst[j] = gbase[my_hi[it]] + my_rank[it];
+    }
+  __syncthreads();
+  for (u32 j = threadIdx.x; j < total; j += blockDim.x) words[st_dst[j]] = st_word[j];
+}
+
+// one block per (partition, window): counting sort by the low bucket bits, bucket bounds.
+// Partitions of up to kTwoIters * 1024 entries are read once and leave through LDS in order.
+__global__ __launch_bounds__(1024) void k_two_sort_lo(const u32* __restrict__ words,
+                                                      const u32* __restrict__ part_count, size_t n, u32 n_hi,
+                                                      u32 n_buckets, int wshift, u32* __restrict__ sorted_vals,
+                                                      u32* __restrict__ bucket_start, u32* __restrict__ bucket_end) {
+  __shared__ u32 hist[kTwoLo], off[kTwoLo];
+  __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
+  __shared__ u32 staged[kTwoIters * 1024];
+  __shared__ u32 s_start;
+  const u32 h = blockIdx.x, w = blockIdx.y;
+  const u32 m = part_count[w * n_hi + h];
+  if (threadIdx.x < kTwoLo) hist[threadIdx.x] = 0;
+  {
+    const u32 part = two_partition_scan(part_count, w, n_hi, n, wave_sums);  // syncs inside
+    if (threadIdx.x == h) s_start = part;
+  }
+  __syncthreads();
+  const u32 s = s_start;
+  const u32 idx_mask = (1u << kTwoIdxBits) - 1u, wbits = w << wshift;
+  const bool cached = m <= (u32)kTwoIters * 1024u;
+  u32 my_word[kTwoIters], my_rank[kTwoIters];
+  if (cached) {
+#pragma unroll
+    for (int it = 0; it < kTwoIters; it++) {
+      const u32 p = (u32)it * 1024u + threadIdx.x;
+      const bool valid = p < m;
+      const u32 word = valid ? words[s + p] : 0u;
+      my_word[it] = word;
+      my_rank[it] = lds_rank(hist, (word >> kTwoIdxBits) & (kTwoLo - 1), valid);
+    }
+  } else {
+    for (u32 p0 = 0; p0 < m; p0 += 1024u) {
+      const u32 p = p0 + threadIdx.x;
+      const bool valid = p < m;
+      const u32 word = valid ? words[s + p] : 0u;
+      lds_rank(hist, (word >> kTwoIdxBits) & (kTwoLo - 1), valid);
+    }
+  }
+  __syncthreads();
+  u32 total;
+  const u32 mine = threadIdx.x < kTwoLo ? hist[threadIdx.x] : 0u;
+  const u32 before = block_exclusive_scan(mine, wave_sums, &total);
+  if (threadIdx.x < kTwoLo) {
+    off[threadIdx.x] = before;
+    const size_t gb = (size_t)w * n_buckets + (size_t)h * kTwoLo + threadIdx.x;
+    bucket_start[gb] = s + before;
+    bucket_end[gb] = s + before + mine;
+  }
+  __syncthreads();
+  if (cached) {
+#pragma unroll
+    for (int it = 0; it < kTwoIters; it++) {
+      const u32 p = (u32)it * 1024u + threadIdx.x;
+      if (p < m) {
+        const u32 word = my_word[it];
+        staged[off[(word >> kTwoIdxBits) & (kTwoLo - 1)] + my_rank[it]] = (word & idx_mask) | wbits | (word & 0x80000000u);
+      }
+    }
+    __syncthreads();
+    for (u32 p = threadIdx.x; p < m; p += blockDim.x) sorted_vals[s + p] = staged[p];
+  } else {
+    // too many entries to keep: read them again, off[] now counts upwards as the cursor
+    for (u32 p0 = 0; p0 < m; p0 += 1024u) {
+      const u32 p = p0 + threadIdx.x;
+      const bool valid = p < m;
+      const u32 word = valid ? words[s + p] : 0u;
+      const u32 pos = lds_rank(off, (word >> kTwoIdxBits) & (kTwoLo - 1), valid);
+      if (valid) sorted_vals[s + pos] = (word & idx_mask) | wbits | (word & 0x80000000u);
+    }
   }
 }
 
@@ -1300,6 +1558,7 @@ hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int
 static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st,
                                hipEvent_t ev_acc0, hipEvent_t ev_acc1, const u32* table_rec = nullptr);
 static hipError_t msm_sort_and_chunk(const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st, u32 window_base);
+static hipError_t msm_chunk_table(const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st);
 static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st,
                                  hipEvent_t ev_acc0, hipEvent_t ev_acc1, const u32* table_rec);
 static hipError_t msm_reduce(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st);
@@ -1364,6 +1623,26 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
                        tab, tab ? table->stride : 0, p0.tab_offset, p1.tab_offset, ws.vals_b);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1, tab ? table->rec : nullptr);
+  }
+  if (plan.two_level) {
+    const u32 n_hi = plan.n_buckets >> kTwoLoBits;
+    // counters live in the chunk-offset array, which is not written before the chunk table
+    u32* part_count = ws.choff;
+    u32* cursor = ws.choff + kTwoMaxBins;
+    uint16_t* digits = (uint16_t*)ws.keys_b;
+    uint8_t* flips = (uint8_t*)ws.vals_a;
+    if ((e = hipMemsetAsync(part_count, 0, 2 * kTwoMaxBins * sizeof(u32), st)) != hipSuccess) return e;
+    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_two_digits<C>, dim3((unsigned)((n + kTwoDigitPoints - 1) / kTwoDigitPoints)),
+                                             dim3(1024), 0, st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x, p0.y, p1.x,
+                                             p1.y, plan.c, plan.n_windows, n_hi, ws.packed, digits, flips, part_count));
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_two_scatter, dim3((unsigned)((n + kTwoScatterPoints - 1) / kTwoScatterPoints), (unsigned)plan.n_windows),
+                       dim3(1024), 0, st, digits, flips, part_count, n, n_hi, cursor, ws.keys_a);
+    hipLaunchKernelGGL(k_two_sort_lo, dim3(n_hi, (unsigned)plan.n_windows), dim3(1024), 0, st, ws.keys_a, part_count, n,
+                       n_hi, plan.n_buckets, plan.wshift, ws.vals_b, ws.bucket_start, ws.bucket_end);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = msm_chunk_table(plan, ws, st)) != hipSuccess) return e;
+    return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
   }
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_digits<C>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                            st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, plan.c,
@@ -1430,7 +1709,6 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
 // chunked path, after the digits: radix sort of (bucket, entry) pairs, bucket bounds, chunk table
 // sorted by chunk length.  window_base = number of the first window of the entries given.
 static hipError_t msm_sort_and_chunk(const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st, u32 window_base) {
-  const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
   hipError_t e;
   size_t tmp = plan.sort_tmp_bytes;
   e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
@@ -1442,6 +1720,14 @@ static hipError_t msm_sort_and_chunk(const MsmPlan& plan, const MsmWorkspace& ws
   hipLaunchKernelGGL(k_bounds, dim3((unsigned)((plan.entries + 255) / 256)), dim3(256), 0, st, ws.keys_b,
                      ws.vals_b, plan.entries, plan.n_buckets, plan.wshift, window_base, ws.bucket_start, ws.bucket_end);
   if ((e = hipGetLastError()) != hipSuccess) return e;
+  return msm_chunk_table(plan, ws, st);
+}
+
+// chunk table of sorted entries with known bucket bounds, sorted by chunk length
+static hipError_t msm_chunk_table(const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st) {
+  const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
+  hipError_t e;
+  size_t tmp;
   hipLaunchKernelGGL(k_chunk_counts, dim3((unsigned)((nbt + 256) / 256)), dim3(256), 0, st, ws.bucket_start,
                      ws.bucket_end, nbt, plan.chunk, ws.nch);
   if ((e = hipGetLastError()) != hipSuccess) return e;

@@ -7,7 +7,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-last = max(i for i, r in enumerate(rows) if "k_digits" in r["Kernel_Name"])
+last = max(i for i, r in enumerate(rows) if "digits" in r["Kernel_Name"])
 t0 = int(rows[last]["Start_Timestamp"])
 for r in rows[last:]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
