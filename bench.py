@@ -135,6 +135,38 @@ def range_proofs(ctx, device, workers=8, per_worker=8):
     }
 
 
+def msm_in_flight(bp, device, dx, dy, dk, n, steps, workers=2):
+    """MSM throughput with `workers` host threads, one context (stream and workspace) each, over the
+    same resident inputs: the tail of one MSM (bucket reduction, a dependent chain on few lanes)
+    overlaps the front of the next.  Reported beside the headline figure, never as it."""
+    import threading
+
+    import torch
+
+    ctxs = [bp.Context(device) for _ in range(workers)]
+    for c in ctxs:
+        c.msm_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n)
+    torch.cuda.synchronize()
+    gate = threading.Barrier(workers + 1)
+
+    def run(c):
+        gate.wait()
+        for _ in range(steps):
+            c.msm_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n)
+
+    threads = [threading.Thread(target=run, args=(c,)) for c in ctxs]
+    for t in threads:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": workers * steps * n / dt, "unit": "points/s", "workers": workers, "steps_each": steps,
+            "ms_per_msm": dt / (workers * steps) * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +175,7 @@ def main():
     ap.add_argument("--log2n", type=int, default=LOG2_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-range", action="store_true", help="skip the aggregated range proof figures")
+    ap.add_argument("--no-in-flight", action="store_true", help="skip the two-MSMs-in-flight figure")
     args = ap.parse_args()
 
     import torch
@@ -250,6 +283,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n)
         if not args.no_range and world == 1:
             out["range_proofs"] = range_proofs(ctx, local_rank)
+        if world == 1 and not args.no_in_flight:
+            out["msm_two_in_flight"] = msm_in_flight(bp, local_rank, dx, dy, dk, n, args.steps)
         assert res is not None
         print(json.dumps(out), flush=True)
     if use_dist:

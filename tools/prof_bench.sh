@@ -4,7 +4,7 @@
 tag=$1; shift
 out=/root/repo/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 -u /root/repo/bench.py --no-cpu-baseline "$@" > $out.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 -u /root/repo/bench.py --no-cpu-baseline --no-range --no-in-flight "$@" > $out.log 2>&1
 tail -1 $out.log | cut -c1-200
 python3 - <<PY
 import csv, glob
