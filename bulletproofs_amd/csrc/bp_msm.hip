@@ -168,8 +168,9 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
     size_t per_bucket = n_total / (size_t)groups / p.n_buckets + 1;
     u32 bal = 1;
     while ((size_t)bal * bal * 10 < per_bucket * 14) bal++;
-    if (getenv("BP_MSM_CHUNK")) bal = (u32)atoi(getenv("BP_MSM_CHUNK"));
     if (bal > p.chunk && bal <= 32) p.chunk = bal;
+    if (getenv("BP_MSM_CHUNK")) p.chunk = (u32)atoi(getenv("BP_MSM_CHUNK"));  // tuning runs
+    if (p.chunk < 1) p.chunk = 1;
   }
   // very large inputs: about 2^21 chunks are plenty of lanes, and longer chunks keep the
   // number of partial sums per bucket small
