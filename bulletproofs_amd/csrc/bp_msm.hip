@@ -56,7 +56,7 @@ constexpr int kMidIters = 8;
 constexpr u32 kMidSlice = kSmallThreads * kMidIters;
 constexpr u32 kMidMaxBuckets = 256;
 constexpr int kTwoLevelLoBits = 8;       // see the two-level counting sort
-constexpr u32 kTwoLevelMaxBins = 2048;
+constexpr u32 kTwoLevelMaxBins = 4096;
 constexpr int kTwoLevelIdxBits = 22;
 
 static inline int ilog2_floor(size_t n) {
@@ -186,10 +186,11 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
     size_t need = (size_t)p.n_windows * (p.tab ? p.entries : n_total) * sizeof(u32);
     if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
   }
-  // single sums on the chunked path sort with the two-level counting sort when the bucket
-  // number has a high part and the counters of all (window, partition) pairs fit one block
-  p.two_level = !p.small && !p.mid && !p.tab && groups == 1 && p.stages == 1 && n_total > 0 &&
+  // the chunked path sorts with the two-level counting sort when the bucket number has a high
+  // part and the counters of all (window, partition) pairs fit one block
+  p.two_level = !p.small && !p.mid && !p.tab && p.stages == 1 && n_total > 0 &&
                 n_total <= ((size_t)1 << kTwoLevelIdxBits) && p.n_buckets >= (2u << kTwoLevelLoBits) &&
+                (size_t)groups * (p.n_buckets >> kTwoLevelLoBits) <= (1u << kTwoLevelLoBits) &&
                 (size_t)p.n_windows * (p.n_buckets >> kTwoLevelLoBits) <= kTwoLevelMaxBins &&
                 nbt + 2 >= 2 * (size_t)kTwoLevelMaxBins && !getenv("BP_MSM_RADIX");
   p.nch_bytes = ((nbt + 2 + kMsmMaxStages) * sizeof(u32) + 255) & ~(size_t)255;
@@ -748,14 +749,16 @@ __global__ __launch_bounds__(1024) void k_two_digits(const u32* __restrict__ s0,
                                                      size_t n0, const u32* __restrict__ s1,
                                                      const uint8_t* __restrict__ inf1, size_t n1,
                                                      const u32* __restrict__ x0, const u32* __restrict__ y0,
-                                                     const u32* __restrict__ x1, const u32* __restrict__ y1, int c,
-                                                     int n_windows, u32 n_hi, u32* __restrict__ packed,
+                                                     const u32* __restrict__ x1, const u32* __restrict__ y1,
+                                                     DigitGroups sel, int c, int group_windows, int groups,
+                                                     u32 n_hi, u32* __restrict__ packed,
                                                      uint16_t* __restrict__ digits, uint8_t* __restrict__ flips,
                                                      u32* __restrict__ part_count) {
   using Fr = typename C::Fr;
   __shared__ u32 hist[kTwoMaxBins];
-  const size_t n = n0 + n1;
-  const u32 bins = (u32)n_windows * n_hi;
+  const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
+  const int n_windows = group_windows;  // digit windows; output window = group * group_windows + w
+  const u32 bins = (u32)(groups * group_windows) * n_hi;
   for (u32 q = threadIdx.x; q < bins; q += blockDim.x) hist[q] = 0;
   __syncthreads();
   const u32 half = 1u << (c - 1), mask = (1u << c) - 1;
@@ -763,17 +766,24 @@ __global__ __launch_bounds__(1024) void k_two_digits(const u32* __restrict__ s0,
     const size_t i = (size_t)blockIdx.x * kTwoDigitPoints + (size_t)it * 1024 + threadIdx.x;
     const bool live = i < n;
     const size_t ii = live ? i : 0;
-    const bool second = ii >= n0;
+    const bool second = ii >= n0, is_extra = ii >= n01;
+    const u32 wbase = (groups > 1 ? digit_group_of(sel, ii, n0, n01) : 0u) * (u32)group_windows;
     Fe k = fe_zero();
     bool is_inf = true;
     u32 flip = 0;
     if (live) {
       const u32* px = second ? x1 + (ii - n0) * 8 : x0 + ii * 8;
       const u32* py = second ? y1 + (ii - n0) * 8 : y0 + ii * 8;
+      const u32* sp = second ? s1 + (ii - n0) * 8 : s0 + ii * 8;
+      if (is_extra) {
+        px = sel.extra_xy[ii - n01];
+        py = px + 8;
+        sp = sel.extra_s[ii - n01];
+      }
       fe_store(packed + ii * 16, fe_load(px));
       fe_store(packed + ii * 16 + 8, fe_load(py));
-      is_inf = second ? (inf1 && inf1[ii - n0]) : (inf0 && inf0[ii]);
-      k = fe_from_mont<Fr>(fe_load(second ? s1 + (ii - n0) * 8 : s0 + ii * 8));
+      is_inf = is_extra ? false : (second ? (inf1 && inf1[ii - n0]) : (inf0 && inf0[ii]));
+      k = fe_from_mont<Fr>(fe_load(sp));
       // |k| <= r/2: use r - k with the point negated when that is the smaller value
       Fe nk = fe_neg<Fr>(k);
       bool gt = false, decided = false;
@@ -818,7 +828,7 @@ __global__ __launch_bounds__(1024) void k_two_digits(const u32* __restrict__ s0,
       const bool valid = live && !is_inf && mag != 0;
       const u32 key = mag - 1;
       if (live) digits[(size_t)w * n + ii] = valid ? (uint16_t)(key | (neg << 15)) : kTwoNoDigit;
-      lds_rank(hist, (u32)w * n_hi + (key >> kTwoLoBits), valid);
+      lds_rank(hist, (wbase + (u32)w) * n_hi + (key >> kTwoLoBits), valid);
     }
   }
   __syncthreads();
@@ -826,22 +836,28 @@ __global__ __launch_bounds__(1024) void k_two_digits(const u32* __restrict__ s0,
     if (hist[q]) atomicAdd(&part_count[q], hist[q]);
 }
 
-// start of partition h of window w inside the window's slice of n entries; every lane of the
-// block calls (blockDim = 1024)
-__device__ __forceinline__ u32 two_partition_scan(const u32* __restrict__ part_count, u32 w, u32 n_hi, size_t n,
-                                                  u32* wave_sums) {
+// Digit window w owns entries [w*n, (w+1)*n) of the sorted array, group 0 first (size0 = points of
+// group 0), so output window wid = g*group_windows + w starts at w*n + g*size0.  Returns the start
+// of partition `threadIdx.x` of window wid (lanes < n_hi); every lane of the block calls.
+__device__ __forceinline__ u32 two_partition_scan(const u32* __restrict__ part_count, u32 wid, u32 group_windows,
+                                                  u32 n_hi, size_t n, size_t size0, u32* wave_sums) {
   u32 total;
-  const u32 mine = threadIdx.x < n_hi ? part_count[w * n_hi + threadIdx.x] : 0u;
-  return (u32)((size_t)w * n) + block_exclusive_scan(mine, wave_sums, &total);
+  const u32 mine = threadIdx.x < n_hi ? part_count[wid * n_hi + threadIdx.x] : 0u;
+  const size_t base = (size_t)(wid % group_windows) * n + (size_t)(wid / group_windows) * size0;
+  return (u32)base + block_exclusive_scan(mine, wave_sums, &total);
 }
 
 // word: point index | low bucket bits << kTwoIdxBits | sign << 31.  The block's entries are
 // ordered by partition in LDS first, so that what goes to one partition leaves as one run.
 __global__ __launch_bounds__(1024) void k_two_scatter(const uint16_t* __restrict__ digits,
                                                       const uint8_t* __restrict__ flips,
-                                                      const u32* __restrict__ part_count, size_t n, u32 n_hi,
-                                                      u32* __restrict__ cursor, u32* __restrict__ words) {
-  __shared__ u32 hist[kTwoLo], gbase[kTwoLo], loff[kTwoLo];  // n_hi <= kTwoLo
+                                                      const u32* __restrict__ part_count, DigitGroups sel,
+                                                      size_t n0, size_t n1, size_t size0, u32 group_windows,
+                                                      u32 groups, u32 n_hi, u32* __restrict__ cursor,
+                                                      u32* __restrict__ words) {
+  __shared__ u32 hist[kTwoLo], gbase[kTwoLo], loff[kTwoLo];  // bins of a block: groups * n_hi <= kTwoLo
+  const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
+  const u32 bins = groups * n_hi;
   __shared__ u32 st_word[kTwoScatterPoints], st_dst[kTwoScatterPoints];
   __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
   const u32 w = blockIdx.y;
@@ -860,23 +876,34 @@ __global__ __launch_bounds__(1024) void k_two_scatter(const uint16_t* __restrict
     }
     const bool valid = d != kTwoNoDigit;
     const u32 key = d & 0x7fffu, sign = (d >> 15) ^ flip;
-    my_hi[it] = valid ? key >> kTwoLoBits : n_hi;
+    const u32 grp = groups > 1 && i < n ? digit_group_of(sel, i, n0, n01) : 0u;
+    const u32 bin = grp * n_hi + (key >> kTwoLoBits);
+    my_hi[it] = valid ? bin : bins;
     my_word[it] = (u32)i | ((key & (kTwoLo - 1)) << kTwoIdxBits) | (sign << 31);
-    my_rank[it] = lds_rank(hist, key >> kTwoLoBits, valid);
+    my_rank[it] = lds_rank(hist, bin, valid);
   }
   __syncthreads();
-  const u32 part = two_partition_scan(part_count, w, n_hi, n, wave_sums);
+  // partition starts of this digit window in group 0, then group 1
+  u32 part = two_partition_scan(part_count, w, group_windows, n_hi, n, size0, wave_sums);
+  if (groups > 1) {
+    __shared__ u32 part1[kTwoLo];
+    const u32 p1 = two_partition_scan(part_count, group_windows + w, group_windows, n_hi, n, size0, wave_sums);
+    if (threadIdx.x < n_hi) part1[threadIdx.x] = p1;
+    __syncthreads();
+    if (threadIdx.x >= n_hi && threadIdx.x < bins) part = part1[threadIdx.x - n_hi];
+  }
   u32 total;
-  const u32 mine = threadIdx.x < n_hi ? hist[threadIdx.x] : 0u;
+  const u32 mine = threadIdx.x < bins ? hist[threadIdx.x] : 0u;
   const u32 before = block_exclusive_scan(mine, wave_sums, &total);
-  if (threadIdx.x < n_hi) {
+  if (threadIdx.x < bins) {
+    const u32 wid = (threadIdx.x / n_hi) * group_windows + w;
     loff[threadIdx.x] = before;
-    gbase[threadIdx.x] = mine ? part + atomicAdd(&cursor[w * n_hi + threadIdx.x], mine) : 0u;
+    gbase[threadIdx.x] = mine ? part + atomicAdd(&cursor[wid * n_hi + threadIdx.x % n_hi], mine) : 0u;
   }
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < kIters; it++)
-    if (my_hi[it] < n_hi) {
+    if (my_hi[it] < bins) {
       const u32 j = loff[my_hi[it]] + my_rank[it];
       st_word[j] = my_word[it];
       st_dst[j] = gbase[my_hi[it]] + my_rank[it];
@@ -888,8 +915,9 @@ __global__ __launch_bounds__(1024) void k_two_scatter(const uint16_t* __restrict
 // one block per (partition, window): counting sort by the low bucket bits, bucket bounds.
 // Partitions of up to kTwoIters * 1024 entries are read once and leave through LDS in order.
 __global__ __launch_bounds__(1024) void k_two_sort_lo(const u32* __restrict__ words,
-                                                      const u32* __restrict__ part_count, size_t n, u32 n_hi,
-                                                      u32 n_buckets, int wshift, u32* __restrict__ sorted_vals,
+                                                      const u32* __restrict__ part_count, size_t n, size_t size0,
+                                                      u32 group_windows, u32 n_hi, u32 n_buckets, int wshift,
+                                                      u32* __restrict__ sorted_vals,
                                                       u32* __restrict__ bucket_start, u32* __restrict__ bucket_end) {
   __shared__ u32 hist[kTwoLo], off[kTwoLo];
   __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
@@ -899,7 +927,7 @@ __global__ __launch_bounds__(1024) void k_two_sort_lo(const u32* __restrict__ wo
   const u32 m = part_count[w * n_hi + h];
   if (threadIdx.x < kTwoLo) hist[threadIdx.x] = 0;
   {
-    const u32 part = two_partition_scan(part_count, w, n_hi, n, wave_sums);  // syncs inside
+    const u32 part = two_partition_scan(part_count, w, group_windows, n_hi, n, size0, wave_sums);  // syncs inside
     if (threadIdx.x == h) s_start = part;
   }
   __syncthreads();
@@ -1633,14 +1661,30 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     uint16_t* digits = (uint16_t*)ws.keys_b;
     uint8_t* flips = (uint8_t*)ws.vals_a;
     if ((e = hipMemsetAsync(part_count, 0, 2 * kTwoMaxBins * sizeof(u32), st)) != hipSuccess) return e;
+    // points of group 0: its share of every digit window's slice of the sorted entries
+    size_t size0 = 0;
+    if (plan.groups > 1) {
+      const MsmPart* parts[2] = {&p0, &p1};
+      for (const MsmPart* pt : parts) {
+        if (pt->sel_half == 0) {
+          if (pt->group_lo == 0) size0 += pt->n;
+        } else {
+          size0 += (pt->group_lo == 0 ? pt->n / 2 : 0) + (pt->group_hi == 0 ? pt->n / 2 : 0);
+        }
+      }
+      if (extra) size0 += 1;
+    }
+    const unsigned gw = (unsigned)plan.group_windows;
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_two_digits<C>, dim3((unsigned)((n + kTwoDigitPoints - 1) / kTwoDigitPoints)),
                                              dim3(1024), 0, st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x, p0.y, p1.x,
-                                             p1.y, plan.c, plan.n_windows, n_hi, ws.packed, digits, flips, part_count));
+                                             p1.y, sel, plan.c, plan.group_windows, plan.groups, n_hi, ws.packed, digits,
+                                             flips, part_count));
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_two_scatter, dim3((unsigned)((n + kTwoScatterPoints - 1) / kTwoScatterPoints), (unsigned)plan.n_windows),
-                       dim3(1024), 0, st, digits, flips, part_count, n, n_hi, cursor, ws.keys_a);
+    hipLaunchKernelGGL(k_two_scatter, dim3((unsigned)((n + kTwoScatterPoints - 1) / kTwoScatterPoints), gw), dim3(1024), 0,
+                       st, digits, flips, part_count, sel, p0.n, p1.n, size0, gw, (u32)plan.groups, n_hi, cursor,
+                       ws.keys_a);
     hipLaunchKernelGGL(k_two_sort_lo, dim3(n_hi, (unsigned)plan.n_windows), dim3(1024), 0, st, ws.keys_a, part_count, n,
-                       n_hi, plan.n_buckets, plan.wshift, ws.vals_b, ws.bucket_start, ws.bucket_end);
+                       size0, gw, n_hi, plan.n_buckets, plan.wshift, ws.vals_b, ws.bucket_start, ws.bucket_end);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = msm_chunk_table(plan, ws, st)) != hipSuccess) return e;
     return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
