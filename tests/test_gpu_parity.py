@@ -189,6 +189,13 @@ def test_msm_degenerate_distributions_sliced_path(ctx, coracle, c):
     _degenerate_case(ctx, coracle, c, 30000)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_msm_degenerate_distributions_two_level_sort(ctx, coracle, c):
+    """the same at a size that takes the two-level counting sort: every entry of a window in one
+    partition and one bucket (wave-uniform ranking, a partition larger than a block keeps)"""
+    _degenerate_case(ctx, coracle, c, (1 << 18) + 77)
+
+
 def _degenerate_case(ctx, coracle, c, n):
     px, py = seeded_points(coracle, c, n, 99, 101)
     rng = np.random.default_rng(8)
