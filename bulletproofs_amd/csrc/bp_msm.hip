@@ -1807,9 +1807,14 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
     // lanes per bucket: as many as keep the launch at about one wave per SIMD, and at least
     // one per 32 expected entries
     int lanes = 64;
-    while (lanes > 1 && nbt * (size_t)lanes > 65536) lanes >>= 1;
+    size_t lane_cap = 65536;
+    if (const char* ev = getenv("BP_MSM_TREE_LANES")) lane_cap = (size_t)atol(ev);  // tuning runs
+    while (lanes > 1 && nbt * (size_t)lanes > lane_cap) lanes >>= 1;
     const size_t per_bucket = plan.entries / (nbt ? nbt : 1);
     while (lanes < 64 && (size_t)lanes * 32 < per_bucket) lanes <<= 1;
+    // no more lanes than expected entries: every halving saves a level of the shuffle tree
+    // (IPA round at 64 points: 0.21 -> 0.17 ms)
+    while (lanes > 1 && (size_t)lanes > (per_bucket ? per_bucket : 1)) lanes >>= 1;
     // a bucket with more than twice the expected entries per lane (and more than 16 per lane)
     // would set the length of the launch's chain: it goes to a block of its own.  A scalar
     // field well below 2^256 fills its top window this unevenly on every input.
