@@ -560,13 +560,21 @@ def test_ipa_mid_size_rounds_with_u(ctx, coracle, variant):
 
 
 def test_ipa_large_first_round_with_u(ctx, coracle):
-    """n = 2^17: 2^18 + 2 points in two groups take the 16-bit-window pipeline; the first
-    round's L and R equal the C oracle's MSMs plus c*u"""
+    """n = 2^17: 2^18 + 2 points in two groups, the largest input of the sliced counting sort;
+    the first round's L and R equal the C oracle's MSMs plus c*u"""
     _ipa_rounds_with_u(ctx, coracle, 0, 17, 1, full=False)
 
 
-def _ipa_rounds_with_u(ctx, coracle, variant, k, checked_rounds, full=True):
-    c = o.SECP256K1
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_ipa_first_round_16_bit_windows(ctx, coracle, c, variant):
+    """n = 2^18 (variant 1: 2^19): two groups of 2^18 points and the extra point u take the
+    16-bit-window pipeline with the two-level counting sort; L and R of the first round equal
+    the C oracle's MSMs plus c*u"""
+    _ipa_rounds_with_u(ctx, coracle, variant, 18 + variant, 1, full=False, c=c)
+
+
+def _ipa_rounds_with_u(ctx, coracle, variant, k, checked_rounds, full=True, c=o.SECP256K1):
     n = 1 << k
     gx, gy = seeded_points(coracle, c, n, 17, 19)
     hx, hy = seeded_points(coracle, c, n, 900001, 23)
