@@ -78,6 +78,7 @@ SIGNATURES = {
     "bp_fold_scalars": (ci, [vp, ci, vp, vp, sz, vp, vp, vp]),
     "bp_vec_op": (ci, [vp, ci, ci, vp, vp, vp, sz, vp]),
     "bp_s_vector": (ci, [vp, ci, vp, vp, sz, vp]),
+    "bp_fold_s_vectors": (ci, [vp, ci, vp, vp, vp, sz, sz, vp]),
     "bp_powers": (ci, [vp, ci, vp, sz, vp]),
     "bp_batch_inverse": (ci, [vp, ci, ci, vp, sz]),
     "bp_fold_generators": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),

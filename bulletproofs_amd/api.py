@@ -171,6 +171,18 @@ class Context:
         self._chk(lib.bp_s_vector(self.h, curve, _p(ch), _p(chi), k, _p(out)))
         return out
 
+    def fold_s_vectors(self, curve, challenges, challenge_inverses, weights):
+        """sum_i weights[i] * s_vector(challenges[i], challenge_inverses[i]); challenges: (m, k, 4)"""
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64)
+        chi = np.ascontiguousarray(challenge_inverses, dtype=np.uint64)
+        w = _f(weights)
+        if ch.ndim != 3 or ch.shape != chi.shape or ch.shape[2] != 4 or w.shape[0] != ch.shape[0] or ch.shape[0] == 0:
+            raise ValueError("challenges must be (m, k, 4) with m >= 1, one weight per row")
+        m, k = ch.shape[0], ch.shape[1]
+        out = np.zeros((1 << k, 4), dtype=np.uint64)
+        self._chk(lib.bp_fold_s_vectors(self.h, curve, _p(ch), _p(chi), _p(w), k, m, _p(out)))
+        return out
+
     def powers(self, curve, x, n):
         x = _f(x)
         out = np.zeros((n, 4), dtype=np.uint64)

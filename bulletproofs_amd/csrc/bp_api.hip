@@ -632,6 +632,30 @@ static int s_vector_common(bp_ctx* ctx, int curve, const uint64_t* ch, const uin
   return BP_OK;
 }
 
+int bp_fold_s_vectors(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_inv, const uint64_t* weights,
+                      size_t k, size_t m, uint64_t* out) {
+  if (!ctx || !out || !m || !weights || (k && (!ch || !ch_inv))) return fail(ctx, BP_E_ARG, "bp_fold_s_vectors: null argument");
+  if (k > 28) return fail(ctx, BP_E_ARG, "bp_fold_s_vectors: k > 28");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  const size_t n = (size_t)1 << k;
+  void *dch = nullptr, *dchi = nullptr, *dtab, *dacc;
+  if (k) {
+    CHK(upload(ctx, S_IN0, ch, m * k * 32, &dch));
+    CHK(upload(ctx, S_IN1, ch_inv, m * k * 32, &dchi));
+  }
+  CHK(reserve(ctx, S_TABLE, s_vector_table_elems((int)k) * 32, &dtab));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dacc));
+  for (size_t i = 0; i < m; i++) {
+    hipError_t e = launch_s_vector_axpy(curve, (const u32*)dch + i * k * 8, (const u32*)dchi + i * k * 8, (int)k,
+                                        to_arg(weights + 4 * i), i == 0, (u32*)dtab, (u32*)dacc, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "s_vector_axpy", e);
+  }
+  HIPCHK(ctx, hipMemcpyAsync(out, dacc, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
 int bp_s_vector_dev(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_inv, size_t k, uint64_t* d_out) {
   if (!ctx || !d_out || (k && (!ch || !ch_inv))) return fail(ctx, BP_E_ARG, "bp_s_vector_dev: null argument");
   if (k > 28) return fail(ctx, BP_E_ARG, "bp_s_vector_dev: k > 28");

@@ -30,6 +30,9 @@ hipError_t launch_vec_op(int curve, int op, const u32* a, const u32* b, FeArg s,
 // ch, ch_inv: k elements each; table: >= (2^lo + 2^(k-lo)) * 8 u32 with lo = min(k, 8)
 hipError_t launch_s_vector(int curve, const u32* ch, const u32* ch_inv, int k, u32* table, u32* out,
                            hipStream_t st);
+// acc (2^k elements) += w * s_vector(ch, ch_inv); first != 0 overwrites acc.  w in Montgomery form.
+hipError_t launch_s_vector_axpy(int curve, const u32* ch, const u32* ch_inv, int k, FeArg w, int first, u32* table,
+                                u32* acc, hipStream_t st);
 size_t s_vector_table_elems(int k);
 // table: >= (256 + ceil(n/256)) * 8 u32
 hipError_t launch_powers(int curve, FeArg x, size_t n, u32* table, u32* out, hipStream_t st);

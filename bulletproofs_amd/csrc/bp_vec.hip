@@ -239,6 +239,38 @@ hipError_t launch_s_vector(int curve, const u32* ch, const u32* ch_inv, int k, u
   return hipGetLastError();
 }
 
+// acc += w * s-vector, straight from the tables (first != 0: acc = w * s-vector): the running
+// sum of fold_todos_witness (src/poly_commit/mod.rs:228-244) without an s-vector in memory
+template <class F>
+__global__ __launch_bounds__(256) void k_svec_expand_axpy(const u32* __restrict__ table, int k, int lo, FeArg wa,
+                                                          int first, u32* __restrict__ acc) {
+  const Fe w = arg_to_fe(wa);
+  size_t n = (size_t)1 << k, n_lo = (size_t)1 << lo;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    Fe a = fe_load(table + (i & (n_lo - 1)) * 8);
+    Fe b = fe_mul<F>(w, fe_load(table + (n_lo + (i >> lo)) * 8));
+    Fe v = fe_mul<F>(a, b);
+    if (!first) v = fe_add<F>(v, fe_load(acc + i * 8));
+    fe_store(acc + i * 8, v);
+  }
+}
+
+hipError_t launch_s_vector_axpy(int curve, const u32* ch, const u32* ch_inv, int k, FeArg w, int first, u32* table,
+                                u32* acc, hipStream_t st) {
+  int lo = k < kSvecLoBits ? k : kSvecLoBits;
+  size_t nt = s_vector_table_elems(k);
+  size_t n = (size_t)1 << k;
+  unsigned tb = (unsigned)((nt + 255) / 256);
+  unsigned eb = (unsigned)((n + 255) / 256);
+  if (eb > 8192) eb = 8192;
+  DISPATCH_FR(curve, {
+    hipLaunchKernelGGL(k_svec_tables<F>, dim3(tb), dim3(256), 0, st, ch, ch_inv, k, lo, table);
+    hipLaunchKernelGGL(k_svec_expand_axpy<F>, dim3(eb), dim3(256), 0, st, table, k, lo, w, first, acc);
+  });
+  return hipGetLastError();
+}
+
 // ---- powers: out[i] = x^i  (src/poly_commit/mod.rs:16-22) --------------------
 size_t powers_table_elems(size_t n) { return 256 + (n + 255) / 256; }
 

@@ -190,22 +190,22 @@ struct PolyCommit {
   // fold_todos_witness, src/poly_commit/mod.rs:228-244: sum_i alpha^i * coeffs(h_poly_i), r = 0
   static std::vector<Scalar> fold_todos_witness(bp_ctx* ctx, const std::vector<Todo>& todos, const Scalar& alpha) {
     if (todos.empty()) throw std::invalid_argument("Non empty statement list");
-    const size_t k = todos[0].ui.size(), n = (size_t)1 << k;
-    std::vector<Scalar> acc(n), ss(n), next(n);
+    const size_t k = todos[0].ui.size(), n = (size_t)1 << k, m = todos.size();
+    // all h_poly coefficient vectors are built and summed on the device (bp_fold_s_vectors)
+    std::vector<Scalar> acc(n), ch(m * k), chi(m * k), w(m);
     Scalar ai = S::one();
-    for (size_t i = 0; i < todos.size(); i++) {
-      std::vector<Scalar> uinv(k);
-      for (size_t j = 0; j < k; j++) uinv[j] = S::inv(todos[i].ui[j]);
-      Scalar dummy = S::one();
-      check(ctx, bp_s_vector(ctx, CURVE, k ? todos[i].ui[0].l : dummy.l, k ? uinv[0].l : dummy.l, k, ss[0].l), "bp_s_vector");
-      if (i == 0) {
-        acc = ss;  // alpha^0
-      } else {
-        check(ctx, bp_vec_op(ctx, CURVE, BP_VEC_AXPY, acc[0].l, ss[0].l, ai.l, n, next[0].l), "axpy");
-        acc.swap(next);
+    for (size_t i = 0; i < m; i++) {
+      if (todos[i].ui.size() != k) throw std::invalid_argument("deferred checks of different sizes");
+      for (size_t j = 0; j < k; j++) {
+        ch[i * k + j] = todos[i].ui[j];
+        chi[i * k + j] = S::inv(todos[i].ui[j]);
       }
+      w[i] = ai;
       ai = S::mul(ai, alpha);
     }
+    Scalar dummy = S::one();
+    check(ctx, bp_fold_s_vectors(ctx, CURVE, k ? ch[0].l : dummy.l, k ? chi[0].l : dummy.l, w[0].l, k, m, acc[0].l),
+          "bp_fold_s_vectors");
     return acc;
   }
 

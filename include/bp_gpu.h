@@ -153,6 +153,12 @@ int bp_vec_op(bp_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t*
  * Swapping ch and ch_inv gives the inverse vector of src/ipa/mod.rs:150-154. */
 int bp_s_vector(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_inv, size_t k,
                 uint64_t* out);
+/* out = sum_{i<m} weights[i] * s_vector(ch + i*k, ch_inv + i*k), 2^k elements: the witness of
+ * fold_todos_witness src/poly_commit/mod.rs:228-244 (weights = alpha^i, one h_poly per deferred
+ * check) accumulated on the device; only the sum crosses to the host.  ch, ch_inv: m x k
+ * scalars, weights: m scalars, m >= 1. */
+int bp_fold_s_vectors(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_inv,
+                      const uint64_t* weights, size_t k, size_t m, uint64_t* out);
 /* out[i] = x^i, i < n: powers_of_x src/poly_commit/mod.rs:16-22, y_vec
  * src/range/aggregate.rs:88-91, hs' scalars src/range/utils.rs:22-29. */
 int bp_powers(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* out);

@@ -128,6 +128,28 @@ def test_large_vectors_vs_c_oracle(ctx, coracle, c):
         assert o.unpack_field(fq, c.p) == o.batch_inversion(vals, c.p)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("k,m", [(0, 1), (1, 3), (5, 1), (9, 4), (13, 7)])
+def test_fold_s_vectors(ctx, c, k, m):
+    """sum_i alpha^i * coeffs(h_poly_i), src/poly_commit/mod.rs:228-244, against one s-vector
+    per deferred check folded with axpy, and against the big-integer oracle at small sizes."""
+    rng = o.SplitMix64(0x5EC + 16 * k + m)
+    ch = [rng.scalars(k, c.n) for _ in range(m)]
+    chi = [[pow(v, -1, c.n) for v in row] for row in ch]
+    w = rng.scalars(m, c.n)
+    CH = np.stack([o.pack_field(r, c.n).reshape(k, 4) for r in ch])
+    CHI = np.stack([o.pack_field(r, c.n).reshape(k, 4) for r in chi])
+    got = ctx.fold_s_vectors(c.id, CH, CHI, o.pack_field(w, c.n))
+    acc = ctx.scale(c.id, ctx.s_vector(c.id, CH[0], CHI[0]), o.pack_field([w[0]], c.n))
+    for i in range(1, m):
+        acc = ctx.axpy(c.id, acc, o.pack_field([w[i]], c.n), ctx.s_vector(c.id, CH[i], CHI[i]))
+    assert np.array_equal(got, acc)
+    if k <= 9:
+        ss = [o.s_vector(ch[i], c.n) for i in range(m)]
+        exp = [sum(w[i] * ss[i][j] for i in range(m)) % c.n for j in range(1 << k)]
+        assert o.unpack_field(got, c.n) == exp
+
+
 # ---- MSM ----------------------------------------------------------------------------
 
 
