@@ -125,6 +125,7 @@ struct MsmPlan {
   int digit_windows;  // windows of the digit decomposition (= group_windows unless tab)
   int stages;     // > 1: the windows are processed in this many consecutive batches on three streams
   bool two_level; // chunked path: two-level counting sort in place of the key-value radix sort
+  bool rowcol;    // bucket reduction by row and column sums of the (n_buckets/256) x 256 bucket matrix
 };
 
 // Large single-sum plans run their windows in batches: sorting and the chunk table of batch

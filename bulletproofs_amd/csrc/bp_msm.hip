@@ -58,6 +58,8 @@ constexpr u32 kMidMaxBuckets = 256;
 constexpr int kTwoLevelLoBits = 8;       // see the two-level counting sort
 constexpr u32 kTwoLevelMaxBins = 4096;
 constexpr int kTwoLevelIdxBits = 22;
+constexpr u32 kRowcolCols = 256;         // columns of the bucket matrix of the row/column reduction
+constexpr int kRowcolStrip = 8;          // buckets a lane adds before the lanes of a row or column join
 
 static inline int ilog2_floor(size_t n) {
   int l = 0;
@@ -141,6 +143,15 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   p.bounds_bytes = ((nbt + 2 + kMsmMaxStages) * sizeof(u32) + 255) & ~(size_t)255;
   p.bucket_bytes = nbt * 4 * 32;
   p.seg_bytes = (size_t)p.n_windows * p.n_segs * 128;
+  // 512..65536 buckets per window: row and column sums instead of segments (see k_rowcol_sums);
+  // the same buffer then holds 256 column sums, n_buckets/256 row sums and two partial results
+  // per window
+  p.rowcol = p.stages == 1 && p.n_buckets >= 2 * kRowcolCols && p.n_buckets <= kRowcolCols * kRowcolCols &&
+             !getenv("BP_MSM_SEGMENTS");
+  if (p.rowcol) {
+    size_t need = (size_t)p.n_windows * (kRowcolCols + p.n_buckets / kRowcolCols + 2) * 128;
+    if (need > p.seg_bytes) p.seg_bytes = need;
+  }
   p.seg_group_bytes = (size_t)p.n_windows * (p.n_segs / 1024 + 1) * 128;
   p.win_bytes = (size_t)p.n_windows * 128;
   p.packed_bytes = (n_total ? n_total : 1) * 64;
@@ -1412,17 +1423,16 @@ __global__ __launch_bounds__(256) void k_bucket_finish_tree(const u32* __restric
 // with exactly b trailing zero bits are the odd blocks of level b, and their sum S_b is
 // the sum of all B whose weight m has bit b set; each S_b is reduced in place by a tree of
 // its own that starts as soon as level b exists, so all of them are complete after
-// log2(NB) - 1 steps of one addition each.  Then V = sum_b 2^b S_b + NB * B_{NB-1} by a
-// pairwise combination (1 + 2 + 4 + ... doublings on the longest path).
+// log2(NB) - 1 steps of one addition each.  Then V = sum_b 2^b S_b + NB * B_{NB-1}.
+// One block; buckets base .. base + nb - 1 of an SoA array with plane stride nbt, nb a power
+// of two in 2..256; the value, doubled post_dbl times, goes to out (XYZZ, 32 words).
 template <class C>
-__global__ __launch_bounds__(256) void k_window_reduce_small(const u32* __restrict__ buckets, size_t nbt,
-                                                             u32 n_buckets, int log_nb,
-                                                             u32* __restrict__ windows) {
+BP_DEV void window_reduce_block(const u32* __restrict__ buckets, size_t nbt, size_t base, u32 nb, int log_nb,
+                                int post_dbl, u32* __restrict__ out) {
   using F = typename C::Fq;
   __shared__ u32 slot[256 * 32];
   __shared__ u32 term[16 * 32];
-  const u32 w = blockIdx.x, tid = threadIdx.x, nb = n_buckets;
-  const size_t base = (size_t)w * nb;
+  const u32 tid = threadIdx.x;
   if (tid < nb) {
     Xyzz v = tid == 0 ? xyzz_identity<F>() : xyzz_load_soa(buckets, nbt, base + tid - 1);
     xyzz_store_aos(slot + tid * 32, v);
@@ -1469,13 +1479,21 @@ __global__ __launch_bounds__(256) void k_window_reduce_small(const u32* __restri
     xyzz_store_aos(term + tid * 32, v);
   }
   __syncthreads();
+  // term b carries the weight 2^(b + post_dbl): every term is doubled by a lane of its own, all
+  // at once (log_nb + post_dbl doublings on the longest path instead of 1 + 2 + 4 + ... one
+  // level after the other), and a tree of plain additions joins them
+  if ((int)tid < n_terms) {
+    Xyzz v = xyzz_load_aos(term + tid * 32);
+    for (int d = 0; d < (int)tid + post_dbl; d++) v = xyzz_dbl<F>(v);
+    xyzz_store_aos(term + tid * 32, v);
+  }
+  __syncthreads();
   for (int sft = 1; sft < n_terms; sft <<= 1) {
     const bool work = (int)tid < n_terms && (tid % (2 * sft)) == 0 && (int)tid + sft < n_terms;
     Xyzz a, o;
     if (work) {
       a = xyzz_load_aos(term + tid * 32);
       o = xyzz_load_aos(term + (tid + sft) * 32);
-      for (int d = 0; d < sft; d++) o = xyzz_dbl<F>(o);
       xyzz_add<F>(a, o);
     }
     __syncthreads();
@@ -1484,8 +1502,92 @@ __global__ __launch_bounds__(256) void k_window_reduce_small(const u32* __restri
   }
   if (tid == 0) {
     Xyzz v = xyzz_load_aos(term);
-    xyzz_store_aos(windows + (size_t)w * 32, v);
+    xyzz_store_aos(out, v);
   }
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void k_window_reduce_small(const u32* __restrict__ buckets, size_t nbt,
+                                                             u32 n_buckets, int log_nb,
+                                                             u32* __restrict__ windows) {
+  window_reduce_block<C>(buckets, nbt, (size_t)blockIdx.x * n_buckets, n_buckets, log_nb, 0,
+                         windows + (size_t)blockIdx.x * 32);
+}
+
+// ---- 5''. bucket reduction by row and column sums -----------------------------------------
+// Window value = sum_j (j+1)*B_j over NB = R*256 buckets.  Written as a matrix B[r][q] with
+// j = 256 r + q the weight is 256 r + (q+1), so the value is
+//   256 * sum_r r*Rsum_r + sum_q (q+1)*Csum_q,   Rsum_r = sum_q B[r][q],  Csum_q = sum_r B[r][q].
+// Every bucket is added twice, as in a running sum, but no partial sum has to be multiplied by
+// the offset of its segment (that multiplication was half of the lane-work of
+// k_reduce_segments), and the two weighted sums that remain have 256 and R terms per window,
+// which is the size window_reduce_block handles.  Lanes of the first row_blocks blocks each add
+// a strip of the buckets of a row (row_lanes lanes per row, lane i takes q = i mod row_lanes:
+// coalesced) and join by a shuffle tree; lanes of the other blocks do the same down a column (col_lanes lanes
+// per column).  Row sum r goes to slot r-1 of the window's row array (row 0 has weight 0; the
+// last slot gets the identity), column sum q to slot q of its column array.
+template <class C>
+__global__ __launch_bounds__(256) void k_rowcol_sums(const u32* __restrict__ buckets, size_t nbt, u32 n_buckets,
+                                                     int n_windows, u32 row_blocks, int row_lanes, int col_lanes,
+                                                     u32* __restrict__ cols, u32* __restrict__ rows) {
+  using F = typename C::Fq;
+  const u32 n_rows = n_buckets / kRowcolCols;
+  Xyzz acc = xyzz_identity<F>();
+  if (blockIdx.x < row_blocks) {
+    const u32 kLanes = (u32)row_lanes;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t row_id = t / kLanes;
+    const u32 i = (u32)(t % kLanes);
+    const bool live = row_id < (size_t)n_windows * n_rows;
+    const u32 w = (u32)(row_id / n_rows), r = (u32)(row_id % n_rows);
+    if (live) {
+      const size_t base = (size_t)w * n_buckets + (size_t)r * kRowcolCols + i;
+      for (u32 q = 0; q < kRowcolCols; q += kLanes) {
+        Xyzz bk = xyzz_load_soa(buckets, nbt, base + q);
+        xyzz_add<F>(acc, bk);
+      }
+    }
+    for (int o = row_lanes >> 1; o > 0; o >>= 1) {
+      Xyzz other = xyzz_shfl_down(acc, o, row_lanes);
+      if ((int)i < o) xyzz_add<F>(acc, other);
+    }
+    if (live && i == 0) {
+      if (r == 0) acc = xyzz_identity<F>();
+      xyzz_store_soa(rows, (size_t)n_windows * n_rows, (size_t)w * n_rows + (r ? r - 1 : n_rows - 1), acc);
+    }
+  } else {
+    const size_t t = (size_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x;
+    const size_t col_id = t / (u32)col_lanes;
+    const u32 i = (u32)(t % (u32)col_lanes);
+    const bool live = col_id < (size_t)n_windows * kRowcolCols;
+    const u32 w = (u32)(col_id / kRowcolCols), q = (u32)(col_id % kRowcolCols);
+    if (live) {
+      const size_t base = (size_t)w * n_buckets + q;
+      for (u32 r = i; r < n_rows; r += (u32)col_lanes) {
+        Xyzz bk = xyzz_load_soa(buckets, nbt, base + (size_t)r * kRowcolCols);
+        xyzz_add<F>(acc, bk);
+      }
+    }
+    for (int o = col_lanes >> 1; o > 0; o >>= 1) {
+      Xyzz other = xyzz_shfl_down(acc, o, col_lanes);
+      if ((int)i < o) xyzz_add<F>(acc, other);
+    }
+    if (live && i == 0) xyzz_store_soa(cols, (size_t)n_windows * kRowcolCols, (size_t)w * kRowcolCols + q, acc);
+  }
+}
+
+// Blocks 0 .. n_windows-1: parts[w] = sum_q (q+1)*Csum_q; blocks n_windows .. 2 n_windows-1:
+// parts[n_windows + w] = 256 * sum_r r*Rsum_r (the row tree is one level shorter, so its eight
+// doublings finish while the column blocks are still at work).  Window value = sum of the two.
+template <class C>
+__global__ __launch_bounds__(256) void k_rowcol_final(const u32* __restrict__ cols, const u32* __restrict__ rows,
+                                                      int n_windows, u32 n_rows, int log_rows,
+                                                      u32* __restrict__ parts) {
+  const bool is_rows = blockIdx.x >= (u32)n_windows;
+  const u32 w = is_rows ? blockIdx.x - (u32)n_windows : blockIdx.x;
+  const u32 nb = is_rows ? n_rows : kRowcolCols;
+  window_reduce_block<C>(is_rows ? rows : cols, (size_t)n_windows * nb, (size_t)w * nb, nb, is_rows ? log_rows : 8,
+                         is_rows ? 8 : 0, parts + (size_t)blockIdx.x * 32);
 }
 
 // ---- 5. bucket reduction ----------------------------------------------------------
@@ -1876,6 +1978,32 @@ static hipError_t msm_reduce(int curve, const MsmPlan& plan, const MsmWorkspace&
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_window_reduce_small<C>, dim3((unsigned)plan.n_windows),
                                              dim3(plan.n_buckets), 0, st, ws.buckets, nbt, plan.n_buckets, log_nb,
                                              ws.windows));
+    return hipGetLastError();
+  }
+  if (plan.rowcol) {
+    const u32 n_rows = plan.n_buckets / kRowcolCols;
+    int log_rows = 0;
+    while ((1u << log_rows) < n_rows) log_rows++;
+    int strip = kRowcolStrip;
+    if (const char* ev = getenv("BP_MSM_ROWCOL_STRIP")) strip = atoi(ev);  // tuning runs
+    if (strip != 4 && strip != 8 && strip != 16 && strip != 32) strip = kRowcolStrip;
+    const int row_lanes = (int)kRowcolCols / strip;
+    int col_lanes = (int)n_rows / strip;
+    if (col_lanes < 1) col_lanes = 1;
+    const size_t nw = (size_t)plan.n_windows;
+    const u32 row_blocks = (u32)((nw * n_rows * (size_t)row_lanes + 255) / 256);
+    const u32 col_blocks = (u32)((nw * kRowcolCols * (size_t)col_lanes + 255) / 256);
+    u32* cols = ws.segs;
+    u32* rows = cols + nw * kRowcolCols * 32;
+    u32* parts = rows + nw * n_rows * 32;
+    DISPATCH_CURVE(curve, {
+      hipLaunchKernelGGL(k_rowcol_sums<C>, dim3(row_blocks + col_blocks), dim3(256), 0, st, ws.buckets, nbt,
+                         plan.n_buckets, plan.n_windows, row_blocks, row_lanes, col_lanes, cols, rows);
+      hipLaunchKernelGGL(k_rowcol_final<C>, dim3(2 * (unsigned)plan.n_windows), dim3(256), 0, st, cols, rows,
+                         plan.n_windows, n_rows, log_rows, parts);
+      hipLaunchKernelGGL(k_window_combine<C>, dim3((plan.n_windows + 63) / 64), dim3(64), 0, st, parts, 2,
+                         plan.n_windows, ws.windows);
+    });
     return hipGetLastError();
   }
   size_t nseg_threads = (size_t)plan.n_windows * plan.n_segs;
