@@ -1051,13 +1051,22 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
   u32* part_l = s->dots;
   u32* part_r = part_l + (size_t)kDotBlocks * 8;
   u32 *d_cl = part_r + (size_t)kDotBlocks * 8, *d_cr = d_cl + 8, *d_scaled = d_cl + 16;
-  hipError_t e = launch_inner_product(s->curve, a_lo, b_hi, h, part_l, d_cl, ctx->stream);
-  if (e == hipSuccess) e = launch_inner_product(s->curve, a_hi, b_lo, h, part_r, d_cr, ctx->stream);
-  if (e == hipSuccess && s->has_u && s->u_scaled)
-    e = launch_vec_op(s->curve, BP_VEC_SCALE, d_cl, nullptr, s->u_factor, 2, d_scaled, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "inner_product", e);
-  e = launch_ipa_scalars(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, n0, h, s->eg, s->eh, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_scalars", e);
+  hipError_t e;
+  if (h <= kIpaPrepMaxHalf) {
+    // short vectors: a round is a chain of launches, so dots, scaling and MSM scalars share one
+    const bool scaled = s->has_u && s->u_scaled;
+    e = launch_ipa_round_prep(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, n0, h,
+                              scaled ? s->u_factor : FeArg{}, scaled ? 1 : 0, s->eg, s->eh, d_cl, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_round_prep", e);
+  } else {
+    e = launch_inner_product(s->curve, a_lo, b_hi, h, part_l, d_cl, ctx->stream);
+    if (e == hipSuccess) e = launch_inner_product(s->curve, a_hi, b_lo, h, part_r, d_cr, ctx->stream);
+    if (e == hipSuccess && s->has_u && s->u_scaled)
+      e = launch_vec_op(s->curve, BP_VEC_SCALE, d_cl, nullptr, s->u_factor, 2, d_scaled, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "inner_product", e);
+    e = launch_ipa_scalars(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, n0, h, s->eg, s->eh, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_scalars", e);
+  }
   // One pass computes both cross terms: group 0 = L, group 1 = R.
   //   L: G_hi with a_lo, H_lo with b_hi (src/ipa/mod.rs:44-54); R: G_lo with a_hi, H_hi with b_lo (:60-70)
   //   poly-commit: L = <g_hi, a_lo>, R = <g_lo, a_hi> (src/poly_commit/mod.rs:78,83)
@@ -1090,8 +1099,7 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
   CHK(reserve_pinned(ctx, plan.win_bytes + 64));
   char* host = (char*)ctx->pinned;
   HIPCHK(ctx, hipMemcpyAsync(host, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(host + plan.win_bytes, d_cl, 32, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(host + plan.win_bytes + 32, d_cr, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(host + plan.win_bytes, d_cl, 64, hipMemcpyDeviceToHost, ctx->stream));  // c_l, c_r
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   msm_collect_times(ctx, true);
   const uint64_t* win = (const uint64_t*)host;
@@ -1115,19 +1123,11 @@ int bp_ipa_round_fold(bp_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]) {
   // H' = x*H_lo + x^-1*H_hi (src/ipa/mod.rs:82) become coefficient updates of the original
   // generators: upper-half G entries and lower-half H entries gain x, the others x^-1.
   const bool has_h = s->variant == BP_IPA_BULLETPROOF;
-  e = launch_ipa_coef_update(s->curve, s->cg, has_h ? s->ch : nullptr, s->n0, h, xm, xim, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_coef_update", e);
-  // Outputs overwrite the low halves in place: output i reads only inputs i and i+h.
-  if (has_h) {
-    // a' = a_lo*x + a_hi*x^-1 ; b' = b_lo*x^-1 + b_hi*x (src/ipa/mod.rs:88-89)
-    e = launch_fold_scalars(s->curve, s->a, s->a + h * 8, h, xm, xim, s->a, ctx->stream);
-    if (e == hipSuccess) e = launch_fold_scalars(s->curve, s->b, s->b + h * 8, h, xim, xm, s->b, ctx->stream);
-  } else {
-    // a' = a_hi*u^-1 + a_lo*u ; b' = b_lo*u^-1 + b_hi*u (src/poly_commit/mod.rs:96-97)
-    e = launch_fold_scalars(s->curve, s->a + h * 8, s->a, h, xim, xm, s->a, ctx->stream);
-    if (e == hipSuccess) e = launch_fold_scalars(s->curve, s->b, s->b + h * 8, h, xim, xm, s->b, ctx->stream);
-  }
-  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "fold_scalars", e);
+  // The same launch folds the scalars; outputs overwrite the low halves in place (output i reads
+  // only inputs i and i+h): a' = a_lo*x + a_hi*x^-1, b' = b_lo*x^-1 + b_hi*x (src/ipa/mod.rs:88-89;
+  // src/poly_commit/mod.rs:96-97 writes the same pair as a_hi*u^-1 + a_lo*u, b_lo*u^-1 + b_hi*u)
+  e = launch_ipa_round_fold(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, s->n0, h, xm, xim, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_round_fold", e);
   s->x_canon.push_back(xc);
   s->xinv_canon.push_back(xic);
   s->n = h;

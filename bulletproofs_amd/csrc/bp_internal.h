@@ -43,6 +43,14 @@ hipError_t launch_batch_inverse(int curve, int field, u32* v, size_t n, hipStrea
 // whose current length is 2*half.
 hipError_t launch_ipa_coef_update(int curve, u32* cg, u32* ch, size_t n0, size_t half, FeArg x, FeArg x_inv,
                                   hipStream_t st);
+// coefficient update and both scalar folds of a round in one launch (a, b folded in place)
+hipError_t launch_ipa_round_fold(int curve, u32* a, u32* b, u32* cg, u32* ch, size_t n0, size_t half, FeArg x,
+                                 FeArg x_inv, hipStream_t st);
+// both inner products of a round (one block), their multiples by `factor` when scale != 0, and the
+// MSM scalars in one launch; half <= kIpaPrepMaxHalf.  dots: c_l, c_r, factor*c_l, factor*c_r
+constexpr size_t kIpaPrepMaxHalf = 16384;
+hipError_t launch_ipa_round_prep(int curve, const u32* a, const u32* b, const u32* cg, const u32* ch, size_t n0,
+                                 size_t half, FeArg factor, int scale, u32* eg, u32* eh, u32* dots, hipStream_t st);
 hipError_t launch_ipa_scalars(int curve, const u32* a, const u32* b, const u32* cg, const u32* ch, size_t n0,
                               size_t half, u32* eg, u32* eh, hipStream_t st);
 hipError_t launch_fill_one(int curve, u32* v, size_t n, hipStream_t st);
@@ -184,6 +192,11 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
                    const MsmWorkspace& ws, hipStream_t st, hipEvent_t ev_acc0, hipEvent_t ev_acc1,
                    const MsmTable* table = nullptr, const MsmPipe* pipe = nullptr);
 // sums n_parts arrays of n_windows XYZZ points window by window into out (n_windows XYZZ)
+// window values of 2..256 buckets per window, four lanes per point addition (bp_reduce.hip)
+hipError_t launch_window_reduce_quad(int curve, const u32* buckets, size_t nbt, u32 n_buckets, int n_windows,
+                                     u32* windows, hipStream_t st);
+hipError_t launch_rowcol_final_quad(int curve, const u32* cols, const u32* rows, int n_windows, u32 n_rows,
+                                    u32* parts, hipStream_t st);
 hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int n_windows, u32* out,
                                  hipStream_t st);
 

@@ -1972,7 +1972,11 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
 // window sums from the bucket sums
 static hipError_t msm_reduce(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st) {
   const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
+  // four lanes per point addition (bp_reduce.hip) unless BP_MSM_REDUCE_SERIAL asks for one
+  static const bool serial_reduce = getenv("BP_MSM_REDUCE_SERIAL") != nullptr;
   if (plan.n_buckets >= 64 && plan.n_buckets <= 256) {
+    if (!serial_reduce)
+      return launch_window_reduce_quad(curve, ws.buckets, nbt, plan.n_buckets, plan.n_windows, ws.windows, st);
     int log_nb = 0;
     while ((1u << log_nb) < plan.n_buckets) log_nb++;
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_window_reduce_small<C>, dim3((unsigned)plan.n_windows),
@@ -1999,8 +2003,13 @@ static hipError_t msm_reduce(int curve, const MsmPlan& plan, const MsmWorkspace&
     DISPATCH_CURVE(curve, {
       hipLaunchKernelGGL(k_rowcol_sums<C>, dim3(row_blocks + col_blocks), dim3(256), 0, st, ws.buckets, nbt,
                          plan.n_buckets, plan.n_windows, row_blocks, row_lanes, col_lanes, cols, rows);
-      hipLaunchKernelGGL(k_rowcol_final<C>, dim3(2 * (unsigned)plan.n_windows), dim3(256), 0, st, cols, rows,
-                         plan.n_windows, n_rows, log_rows, parts);
+      if (serial_reduce) {
+        hipLaunchKernelGGL(k_rowcol_final<C>, dim3(2 * (unsigned)plan.n_windows), dim3(256), 0, st, cols, rows,
+                           plan.n_windows, n_rows, log_rows, parts);
+      } else {
+        hipError_t e = launch_rowcol_final_quad(curve, cols, rows, plan.n_windows, n_rows, parts, st);
+        if (e != hipSuccess) return e;
+      }
       hipLaunchKernelGGL(k_window_combine<C>, dim3((plan.n_windows + 63) / 64), dim3(64), 0, st, parts, 2,
                          plan.n_windows, ws.windows);
     });

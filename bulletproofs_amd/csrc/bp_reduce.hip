@@ -1,0 +1,315 @@
+// Window value of up to 256 buckets in one block, with every point addition spread over
+// four lanes.
+//
+// The kernels that turn bucket sums into a window value are chains of dependent point
+// additions on a few lanes while the rest of the GPU idles, so what counts is the time of
+// ONE addition.  An XYZZ addition is 14 field multiplications, but only four of them are
+// sequential: {U1, U2, S1, S2}, then {P^2, R^2, ZZ1*ZZ2, ZZZ1*ZZZ2}, then {P^3, U1*P^2,
+// ZZ1*ZZ2*P^2}, then {R*(Q - X3), S1*P^3, ZZZ1*ZZZ2*P^3}.  Four adjacent lanes (a quad) take
+// one multiplication of each stage and exchange the products through a private piece of LDS
+// (all four sit in one wave, so a wait on the LDS counter orders the exchange; no block
+// barrier).  Which operand a lane reads is a matter of its address, not of a branch, so the
+// four lanes run one instruction stream.  Doubling is three stages the same way.
+//
+// The algorithm around it is the one of k_window_reduce_small (bp_msm.hip): a binary sum
+// tree built in place, one tree per weight bit, then sum_b 2^b S_b.
+// Stands in for the window sums inside ark-ec 0.5.0 VariableBaseMSM::msm_unchecked
+// (reference call sites: src/msm.rs:84-87, src/ipa/mod.rs:54,70).
+#include "bp_curve.h"
+#include "bp_internal.h"
+
+namespace bp {
+
+#define DISPATCH_CURVE_R(curve, STMT) \
+  switch (curve) {                    \
+    case BP_SECP256K1: {              \
+      using C = Secp256k1;            \
+      STMT;                           \
+    } break;                          \
+    case BP_VESTA: {                  \
+      using C = Vesta;                \
+      STMT;                           \
+    } break;                          \
+    default:                          \
+      return hipErrorInvalidValue;    \
+  }
+
+constexpr int kQuadScratch = 8;  // field elements of exchange space per quad
+constexpr u32 kQuadMaxBuckets = 256;
+// 96 quads: the 96 additions of the widest step at 128 buckets in one pass, the 192 at 256 buckets
+// in two (points, exchange space and terms together stay below 64 KB of LDS)
+constexpr u32 kQuadThreads = 384;
+constexpr int kQuadPasses = 2;
+static_assert(kQuadPasses * (kQuadThreads / 4) * 4 >= 3 * kQuadMaxBuckets, "passes cover the widest step");
+
+// orders a quad's LDS writes before the reads that follow (same wave: LDS operations
+// complete in order) and keeps the compiler from moving either across
+BP_DEV void quad_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
+// coordinate (0 x, 1 y, 2 zz, 3 zzz) that the lane with this role holds when an operation ends
+BP_DEV int quad_coord(int role) { return role == 0 ? 1 : role == 1 ? 0 : role == 2 ? 3 : 2; }
+
+BP_DEV Fe quad_identity_coord(int coord, const Fe& one) { return coord < 2 ? one : fe_zero(); }
+
+// pts[dst] + pts[src] (XYZZ, 32 words each), by the four lanes of a quad.  Nothing is written
+// to pts: on return the lane holds coordinate quad_coord(role) of the sum in `out`, and the
+// result says whether dst changes at all (false: src is the identity).  scr: the quad's
+// exchange space; zero: eight zero words in LDS.
+template <class F>
+BP_DEV bool quad_add(const u32* pts, u32* scr, const u32* zero, u32 dst, u32 src, int role, Fe& out) {
+  const u32* p = pts + dst * 32;
+  const u32* q = pts + src * 32;
+  const int coord = quad_coord(role);
+  const Fe one = fe_one<F>();
+  if (fe_is_zero(fe_load(q + 16))) return false;
+  if (fe_is_zero(fe_load(p + 16))) {
+    out = fe_load(q + coord * 8);
+    return true;
+  }
+  const int hi = role >> 1, odd = role & 1;
+  // stage 1: U1 = X1*ZZ2, U2 = X2*ZZ1, S1 = Y1*ZZZ2, S2 = Y2*ZZZ1
+  {
+    Fe a = fe_load((odd ? q : p) + hi * 8);
+    Fe b = fe_load((odd ? p : q) + 16 + hi * 8);
+    fe_store(scr + role * 8, fe_mul<F>(a, b));
+  }
+  quad_sync();
+  // stage 2: P^2 with P = U2 - U1, R^2 with R = S2 - S1, ZZ1*ZZ2, ZZZ1*ZZZ2
+  Fe pr;  // P on role 0, R on role 1
+  {
+    const u32* a1 = role < 2 ? scr + (2 * role + 1) * 8 : p + 16 + odd * 8;
+    const u32* a2 = role < 2 ? scr + (2 * role) * 8 : zero;
+    const u32* b1 = role < 2 ? a1 : q + 16 + odd * 8;
+    pr = fe_sub<F>(fe_load(a1), fe_load(a2));
+    Fe b = fe_select(role < 2, pr, fe_load(b1));
+    const int flag = fe_is_zero(pr) ? 1 : 0;
+    const int lane0 = (int)(threadIdx.x & 63u) & ~3;
+    const int p_zero = __shfl(flag, lane0, 64), r_zero = __shfl(flag, lane0 + 1, 64);
+    if (p_zero) {
+      // same x: the same point twice (doubled by every lane on its own) or a point and its negative
+      if (r_zero) {
+        Xyzz v;
+        v.x = fe_load(p);
+        v.y = fe_load(p + 8);
+        v.zz = fe_load(p + 16);
+        v.zzz = fe_load(p + 24);
+        v = xyzz_dbl<F>(v);
+        out = coord == 0 ? v.x : coord == 1 ? v.y : coord == 2 ? v.zz : v.zzz;
+      } else {
+        out = quad_identity_coord(coord, one);
+      }
+      return true;
+    }
+    fe_store(scr + (4 + role) * 8, fe_mul<F>(pr, b));
+  }
+  quad_sync();
+  // stage 3: P^3 = P*P^2, Q = U1*P^2, ZZ3 = ZZ1*ZZ2*P^2 (role 3 has nothing to do and repeats Q).
+  // The products replace values that are dead once this stage has read its operands (the quad
+  // runs one instruction stream, so every lane's loads come before any lane's store):
+  // P^3 -> U2's place, Q -> U1's, ZZ3 -> ZZ1*ZZ2's, role 3's -> P^2's.
+  {
+    const u32* a1 = role == 2 ? scr + 6 * 8 : scr;
+    Fe a = fe_select(role == 0, pr, fe_load(a1));
+    Fe pp = fe_load(scr + 4 * 8);
+    u32* d = role == 0 ? scr + 1 * 8 : role == 1 ? scr : role == 2 ? scr + 6 * 8 : scr + 4 * 8;
+    fe_store(d, fe_mul<F>(a, pp));
+  }
+  quad_sync();
+  // stage 4: X3 = R^2 - P^3 - 2Q on every lane; R*(Q - X3), S1*P^3, ZZZ3 = ZZZ1*ZZZ2*P^3
+  Fe x3, m;
+  {
+    Fe ppp = fe_load(scr + 1 * 8), qq = fe_load(scr), rr = fe_load(scr + 5 * 8);
+    x3 = fe_sub<F>(fe_sub<F>(rr, ppp), fe_dbl<F>(qq));
+    const u32* a1 = role == 0 ? scr + 3 * 8 : role == 2 ? scr + 7 * 8 : scr + 2 * 8;
+    const u32* a2 = role == 0 ? scr + 2 * 8 : zero;
+    Fe a = fe_sub<F>(fe_load(a1), fe_load(a2));
+    Fe b = fe_select(role == 0, fe_sub<F>(qq, x3), ppp);
+    m = fe_mul<F>(a, b);
+    if (role == 1) fe_store(scr + 4 * 8, m);
+  }
+  quad_sync();
+  {
+    Fe t = fe_load(role == 3 ? scr + 6 * 8 : scr + 4 * 8);  // ZZ3 for role 3, S1*P^3 otherwise
+    Fe y3 = fe_sub<F>(m, t);
+    out = role == 0 ? y3 : role == 1 ? x3 : role == 2 ? m : t;
+  }
+  return true;
+}
+
+// pt (32 words in LDS, owned by this quad) doubled in place (dbl-2008-s-1, a = 0)
+template <class F>
+BP_DEV void quad_dbl(u32* pt, u32* scr, const u32* zero, int role) {
+  const int coord = quad_coord(role);
+  const Fe one = fe_one<F>();
+  if (fe_is_zero(fe_load(pt + 16)) || fe_is_zero(fe_load(pt + 8))) {
+    quad_sync();
+    fe_store(pt + coord * 8, quad_identity_coord(coord, one));
+    quad_sync();
+    return;
+  }
+  // stage 1: V = U^2 with U = 2Y (role 0), XX = X^2 (role 1); roles 2 and 3 repeat them
+  Fe u = fe_dbl<F>(fe_load(pt + 8));
+  {
+    Fe a = fe_select((role & 1) == 0, u, fe_load(pt));
+    fe_store(scr + role * 8, fe_mul<F>(a, a));
+  }
+  quad_sync();
+  // stage 2: W = U*V, S = X*V, M^2 with M = 3 XX, ZZ3 = V*ZZ
+  Fe mm;  // M
+  {
+    Fe v = fe_load(scr), xx = fe_load(scr + 8);
+    mm = fe_add<F>(fe_dbl<F>(xx), xx);
+    Fe a = fe_load(role == 1 ? pt : role == 3 ? pt + 16 : zero);
+    a = fe_select(role == 0, u, fe_select(role == 2, mm, a));
+    Fe b = fe_select(role == 2, mm, v);
+    fe_store(scr + (4 + role) * 8, fe_mul<F>(a, b));
+  }
+  quad_sync();
+  // stage 3: X3 = M^2 - 2S on every lane; M*(S - X3), W*Y, ZZZ3 = W*ZZZ
+  Fe x3, m;
+  {
+    Fe w = fe_load(scr + 4 * 8), s = fe_load(scr + 5 * 8), m2 = fe_load(scr + 6 * 8);
+    x3 = fe_sub<F>(m2, fe_dbl<F>(s));
+    Fe a = fe_select(role == 0, mm, w);
+    Fe b = fe_load(role == 2 ? pt + 24 : pt + 8);
+    b = fe_select(role == 0, fe_sub<F>(s, x3), b);
+    m = fe_mul<F>(a, b);
+    if (role == 1) fe_store(scr, m);
+  }
+  quad_sync();
+  {
+    Fe t = fe_load(role == 3 ? scr + 7 * 8 : scr);  // ZZ3 for role 3, W*Y otherwise
+    Fe y3 = fe_sub<F>(m, t);
+    Fe out = role == 0 ? y3 : role == 1 ? x3 : role == 2 ? m : t;
+    fe_store(pt + coord * 8, out);
+  }
+  quad_sync();
+}
+
+// Addition number `task` of step t over nb slots: first the nb >> t additions of the sum tree
+// (level t), then for every weight bit b < t one step of the S_b tree (nb >> (t+1) additions each).
+BP_DEV bool quad_task(u32 task, int t, u32 nb, u32& dst, u32& src) {
+  const u32 chain = nb >> t, per = nb >> (t + 1);
+  dst = src = 0;
+  if (task < chain) {
+    dst = task << t;
+    src = dst + (1u << (t - 1));
+    return true;
+  }
+  const u32 q = task - chain;
+  const u32 b = q / per, j = q % per;
+  if (b >= (u32)t) return false;
+  const int r = t - (int)b;  // step number inside the S_b tree
+  const u32 k = j << r;
+  dst = (2 * k + 1) << b;
+  src = (2 * (k + (1u << (r - 1))) + 1) << b;
+  return true;
+}
+
+// V = sum_{m=1}^{nb} m * B_{m-1} over buckets base .. base + nb - 1 of an SoA array with plane
+// stride nbt, nb a power of two in 2..256, doubled post_dbl times, to out (XYZZ, 32 words).
+// One block of kQuadThreads lanes; see k_window_reduce_small in bp_msm.hip for the two trees.
+template <class C>
+BP_DEV void window_reduce_block_quad(const u32* __restrict__ buckets, size_t nbt, size_t base, u32 nb, int log_nb,
+                                     int post_dbl, u32* __restrict__ out) {
+  using F = typename C::Fq;
+  __shared__ u32 slot[kQuadMaxBuckets * 32];
+  __shared__ u32 term[16 * 32];
+  __shared__ u32 scr_all[(kQuadThreads / 4) * kQuadScratch * 8];
+  __shared__ u32 zero[8];
+  const u32 tid = threadIdx.x, quad = tid >> 2;
+  const int role = (int)(tid & 3u), coord = quad_coord(role);
+  u32* scr = scr_all + quad * (kQuadScratch * 8);
+  if (tid < 8) zero[tid] = 0;
+  // slot m = B_{m-1}, slot 0 = identity; one coordinate per lane
+  for (u32 i = tid; i < nb * 4; i += blockDim.x) {
+    const u32 s = i >> 2, c = i & 3;
+    Fe v = s == 0 ? quad_identity_coord((int)c, fe_one<F>()) : fe_load(buckets + ((size_t)c * nbt + base + s - 1) * 8);
+    fe_store(slot + s * 32 + c * 8, v);
+  }
+  __syncthreads();
+  const u32 n_quads = blockDim.x >> 2;
+  static_assert(kQuadPasses == 2, "the step below is written out for two passes");
+  for (int t = 1; t <= log_nb - 1; t++) {
+    Fe v0, v1;
+    u32 dst0, src0, dst1, src1;
+    const bool work0 = quad_task(quad, t, nb, dst0, src0);
+    const bool work1 = quad_task(quad + n_quads, t, nb, dst1, src1);
+    const bool st0 = work0 ? quad_add<F>(slot, scr, zero, dst0, src0, role, v0) : false;
+    const bool st1 = work1 ? quad_add<F>(slot, scr, zero, dst1, src1, role, v1) : false;
+    __syncthreads();
+    if (st0) fe_store(slot + dst0 * 32 + coord * 8, v0);
+    if (st1) fe_store(slot + dst1 * 32 + coord * 8, v1);
+    __syncthreads();
+  }
+  // terms: T_b = S_b = slot[2^b] for b < log_nb, T_{log_nb} = B_{nb-1}; term b is doubled
+  // b + post_dbl times by its own quad, then a tree of additions joins the terms
+  const int n_terms = log_nb + 1;
+  if ((int)quad < n_terms) {
+    Fe v = (int)quad < log_nb ? fe_load(slot + ((size_t)1 << quad) * 32 + coord * 8)
+                              : fe_load(buckets + ((size_t)coord * nbt + base + nb - 1) * 8);
+    fe_store(term + quad * 32 + coord * 8, v);
+    quad_sync();
+    for (int d = 0; d < (int)quad + post_dbl; d++) quad_dbl<F>(term + quad * 32, scr, zero, role);
+  }
+  __syncthreads();
+  for (int sft = 1; sft < n_terms; sft <<= 1) {
+    const bool work = (int)quad < n_terms && (quad % (2 * sft)) == 0 && (int)quad + sft < n_terms;
+    Fe v;
+    bool st = false;
+    if (work) st = quad_add<F>(term, scr, zero, quad, quad + (u32)sft, role, v);
+    __syncthreads();
+    if (st) fe_store(term + quad * 32 + coord * 8, v);
+    __syncthreads();
+  }
+  if (quad == 0) fe_store(out + coord * 8, fe_load(term + coord * 8));
+}
+
+template <class C>
+__global__ __launch_bounds__(kQuadThreads) void k_window_reduce_quad(const u32* __restrict__ buckets, size_t nbt,
+                                                                     u32 n_buckets, int log_nb,
+                                                                     u32* __restrict__ windows) {
+  window_reduce_block_quad<C>(buckets, nbt, (size_t)blockIdx.x * n_buckets, n_buckets, log_nb, 0,
+                              windows + (size_t)blockIdx.x * 32);
+}
+
+// Blocks 0 .. n_windows-1: parts[w] = sum_q (q+1)*Csum_q over the 256 column sums of window w;
+// blocks n_windows .. 2 n_windows-1: parts[n_windows + w] = 256 * sum_r r*Rsum_r over its row
+// sums (see k_rowcol_sums in bp_msm.hip).  Window value = sum of the two parts.
+template <class C>
+__global__ __launch_bounds__(kQuadThreads) void k_rowcol_final_quad(const u32* __restrict__ cols,
+                                                                    const u32* __restrict__ rows, int n_windows,
+                                                                    u32 n_rows, int log_rows,
+                                                                    u32* __restrict__ parts) {
+  const bool is_rows = blockIdx.x >= (u32)n_windows;
+  const u32 w = is_rows ? blockIdx.x - (u32)n_windows : blockIdx.x;
+  const u32 nb = is_rows ? n_rows : 256u;
+  window_reduce_block_quad<C>(is_rows ? rows : cols, (size_t)n_windows * nb, (size_t)w * nb, nb,
+                              is_rows ? log_rows : 8, is_rows ? 8 : 0, parts + (size_t)blockIdx.x * 32);
+}
+
+hipError_t launch_window_reduce_quad(int curve, const u32* buckets, size_t nbt, u32 n_buckets, int n_windows,
+                                     u32* windows, hipStream_t st) {
+  if (n_buckets < 2 || n_buckets > kQuadMaxBuckets || (n_buckets & (n_buckets - 1))) return hipErrorInvalidValue;
+  int log_nb = 0;
+  while ((1u << log_nb) < n_buckets) log_nb++;
+  DISPATCH_CURVE_R(curve, hipLaunchKernelGGL(k_window_reduce_quad<C>, dim3((unsigned)n_windows), dim3(kQuadThreads), 0,
+                                             st, buckets, nbt, n_buckets, log_nb, windows));
+  return hipGetLastError();
+}
+
+hipError_t launch_rowcol_final_quad(int curve, const u32* cols, const u32* rows, int n_windows, u32 n_rows,
+                                    u32* parts, hipStream_t st) {
+  if (n_rows < 2 || n_rows > kQuadMaxBuckets || (n_rows & (n_rows - 1))) return hipErrorInvalidValue;
+  int log_rows = 0;
+  while ((1u << log_rows) < n_rows) log_rows++;
+  DISPATCH_CURVE_R(curve, hipLaunchKernelGGL(k_rowcol_final_quad<C>, dim3(2 * (unsigned)n_windows), dim3(kQuadThreads),
+                                             0, st, cols, rows, n_windows, n_rows, log_rows, parts));
+  return hipGetLastError();
+}
+
+}  // namespace bp

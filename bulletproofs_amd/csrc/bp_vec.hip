@@ -400,6 +400,69 @@ __global__ __launch_bounds__(256) void k_ipa_scalars(const u32* __restrict__ a, 
   if (ch) fe_store(eh + k * 8, fe_mul<F>(fe_load(ch + k * 8), fe_load(b + other * 8)));
 }
 
+// One launch per folded round: the coefficient update above (k < n0) and both scalar folds
+// (k < half), in place: a' = a_lo*x + a_hi*x^-1, b' = b_lo*x^-1 + b_hi*x (src/ipa/mod.rs:88-89;
+// src/poly_commit/mod.rs:96-97 is the same pair written in the other order).  Output k reads
+// only inputs k and k + half, so the low halves can be overwritten.
+template <class F>
+__global__ __launch_bounds__(256) void k_ipa_round_fold(u32* __restrict__ a, u32* __restrict__ b,
+                                                        u32* __restrict__ cg, u32* __restrict__ ch, size_t n0,
+                                                        size_t half, FeArg xa, FeArg xia) {
+  const Fe x = arg_to_fe(xa), xi = arg_to_fe(xia);
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n0) {
+    bool upper = (k & (2 * half - 1)) >= half;
+    fe_store(cg + k * 8, fe_mul<F>(fe_load(cg + k * 8), upper ? x : xi));
+    if (ch) fe_store(ch + k * 8, fe_mul<F>(fe_load(ch + k * 8), upper ? xi : x));
+  }
+  if (k < half) {
+    Fe al = fe_load(a + k * 8), ah = fe_load(a + (k + half) * 8);
+    Fe bl = fe_load(b + k * 8), bh = fe_load(b + (k + half) * 8);
+    fe_store(a + k * 8, fe_add<F>(fe_mul<F>(al, x), fe_mul<F>(ah, xi)));
+    fe_store(b + k * 8, fe_add<F>(fe_mul<F>(bl, xi), fe_mul<F>(bh, x)));
+  }
+}
+
+// One launch per round ahead of its MSM.  Block 0: c_l = <a_lo, b_hi>, c_r = <a_hi, b_lo>
+// (src/ipa/mod.rs:42,58) into dots[0..1] and, when scale != 0, factor*c_l and factor*c_r into
+// dots[2..3] (u given as factor times a registered point).  The other blocks: the MSM scalars
+// of k_ipa_scalars.
+template <class F>
+__global__ __launch_bounds__(1024) void k_ipa_round_prep(const u32* __restrict__ a, const u32* __restrict__ b,
+                                                         const u32* __restrict__ cg, const u32* __restrict__ ch,
+                                                         size_t n0, size_t half, FeArg factor, int scale,
+                                                         u32* __restrict__ eg, u32* __restrict__ eh,
+                                                         u32* __restrict__ dots) {
+  if (blockIdx.x == 0) {
+    __shared__ u32 lds[2 * 16 * 8];
+    Fe accl = fe_zero(), accr = fe_zero();
+    for (size_t i = threadIdx.x; i < half; i += blockDim.x) {
+      Fe al = fe_load(a + i * 8), ah = fe_load(a + (i + half) * 8);
+      Fe bl = fe_load(b + i * 8), bh = fe_load(b + (i + half) * 8);
+      accl = fe_add<F>(accl, fe_mul<F>(al, bh));
+      accr = fe_add<F>(accr, fe_mul<F>(ah, bl));
+    }
+    Fe tl = block_reduce_add<F>(accl, lds);
+    Fe tr = block_reduce_add<F>(accr, lds + 16 * 8);
+    if (threadIdx.x == 0) {
+      fe_store(dots, tl);
+      fe_store(dots + 8, tr);
+      if (scale) {
+        const Fe f = arg_to_fe(factor);
+        fe_store(dots + 16, fe_mul<F>(tl, f));
+        fe_store(dots + 24, fe_mul<F>(tr, f));
+      }
+    }
+    return;
+  }
+  size_t k = (size_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x;
+  if (k >= n0) return;
+  size_t i = k & (2 * half - 1);
+  size_t other = i >= half ? i - half : i + half;
+  fe_store(eg + k * 8, fe_mul<F>(fe_load(cg + k * 8), fe_load(a + other * 8)));
+  if (ch) fe_store(eh + k * 8, fe_mul<F>(fe_load(ch + k * 8), fe_load(b + other * 8)));
+}
+
 template <class F>
 __global__ __launch_bounds__(256) void k_fill_one(u32* __restrict__ v, size_t n) {
   size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -417,6 +480,24 @@ hipError_t launch_ipa_scalars(int curve, const u32* a, const u32* b, const u32* 
                               size_t half, u32* eg, u32* eh, hipStream_t st) {
   unsigned blocks = (unsigned)((n0 + 255) / 256);
   DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipa_scalars<F>, dim3(blocks), dim3(256), 0, st, a, b, cg, ch, n0, half, eg, eh));
+  return hipGetLastError();
+}
+
+hipError_t launch_ipa_round_fold(int curve, u32* a, u32* b, u32* cg, u32* ch, size_t n0, size_t half, FeArg x,
+                                 FeArg x_inv, hipStream_t st) {
+  size_t threads = n0 > half ? n0 : half;
+  unsigned blocks = (unsigned)((threads + 255) / 256);
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipa_round_fold<F>, dim3(blocks), dim3(256), 0, st, a, b, cg, ch, n0, half, x,
+                                        x_inv));
+  return hipGetLastError();
+}
+
+hipError_t launch_ipa_round_prep(int curve, const u32* a, const u32* b, const u32* cg, const u32* ch, size_t n0,
+                                 size_t half, FeArg factor, int scale, u32* eg, u32* eh, u32* dots, hipStream_t st) {
+  if (half > kIpaPrepMaxHalf) return hipErrorInvalidValue;
+  unsigned blocks = 1 + (unsigned)((n0 + 1023) / 1024);
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipa_round_prep<F>, dim3(blocks), dim3(1024), 0, st, a, b, cg, ch, n0, half,
+                                        factor, scale, eg, eh, dots));
   return hipGetLastError();
 }
 
