@@ -5,7 +5,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "bp_host_math.h"
@@ -29,6 +33,56 @@ struct DevBuf {
 
 }  // namespace
 
+// One helper thread per context, started on first use: the host ends of the two sums of an IPA
+// round (some 250 sequential doublings and a field inversion each) run side by side.
+struct HostWorker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool pending = false, quit = false;
+
+  void run() {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv.wait(lk, [this] { return pending || quit; });
+      if (quit) return;
+      lk.unlock();
+      job();
+      lk.lock();
+      pending = false;
+      cv.notify_all();
+    }
+  }
+  // false: no thread could be started (the caller then runs the job itself)
+  bool submit(std::function<void()> f) {
+    std::unique_lock<std::mutex> lk(m);
+    if (!th.joinable()) {
+      try {
+        th = std::thread([this] { run(); });
+      } catch (...) {
+        return false;
+      }
+    }
+    job = std::move(f);
+    pending = true;
+    cv.notify_all();
+    return true;
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [this] { return !pending; });
+  }
+  ~HostWorker() {
+    {
+      std::unique_lock<std::mutex> lk(m);
+      quit = true;
+      cv.notify_all();
+    }
+    if (th.joinable()) th.join();
+  }
+};
+
 struct bp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -44,6 +98,7 @@ struct bp_ctx {
   size_t ipa_cache_bytes = 0;
   MsmPipe pipe;         // second and third stream of large MSMs
   int last_stages = 1;  // batches of the last MSM (its accumulation time is the sum over pipe.cs0/cs1)
+  HostWorker worker;
 };
 
 struct bp_bases {
@@ -1103,8 +1158,16 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   msm_collect_times(ctx, true);
   const uint64_t* win = (const uint64_t*)host;
-  finish_windows(s->curve, win, plan.group_windows, plan.c, l_xyz);
-  finish_windows(s->curve, win + (size_t)plan.group_windows * 16, plan.group_windows, plan.c, r_xyz);
+  {
+    const int curve = s->curve, gw = plan.group_windows, c = plan.c;
+    const uint64_t* win_r = win + (size_t)gw * 16;
+    const bool helped = ctx->worker.submit([=] { finish_windows(curve, win_r, gw, c, r_xyz); });
+    finish_windows(curve, win, gw, c, l_xyz);
+    if (helped)
+      ctx->worker.wait();
+    else
+      finish_windows(curve, win_r, gw, c, r_xyz);
+  }
   memcpy(c_l, host + plan.win_bytes, 32);
   memcpy(c_r, host + plan.win_bytes + 32, 32);
   return BP_OK;
