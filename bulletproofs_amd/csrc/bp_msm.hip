@@ -1254,9 +1254,9 @@ constexpr u32 kTreeHeavyList = 128;  // buckets a block looks at with the defaul
 template <class C>
 __global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ packed, const u32* __restrict__ vals,
                                                      const u32* __restrict__ start, const u32* __restrict__ end,
-                                                     size_t nbt, int lanes, u32 heavy_from, u32 idx_mask,
-                                                     u32* __restrict__ buckets, u32* __restrict__ heavy,
-                                                     u32* __restrict__ heavy_count) {
+                                                     size_t nbt, int lanes, u32 heavy_from, u32 heavy_max,
+                                                     u32 idx_mask, u32* __restrict__ buckets,
+                                                     u32* __restrict__ heavy, u32* __restrict__ heavy_count) {
   using F = typename C::Fq;
   if (blockIdx.x < kTreeHeavyBlocks) {
     __shared__ u32 list[kTreeHeavyList];
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ pac
     for (size_t b = blockIdx.x + (size_t)kTreeHeavyBlocks * threadIdx.x; b < nbt;
          b += (size_t)kTreeHeavyBlocks * blockDim.x) {
       const u32 cnt = end[b] - start[b];
-      if (cnt > heavy_from && cnt <= kTreeHeavyMax) {
+      if (cnt > heavy_from && cnt <= heavy_max) {
         const u32 slot = atomicAdd(&n_list, 1u);
         if (slot < kTreeHeavyList)
           list[slot] = (u32)b;
@@ -1319,7 +1319,7 @@ __global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ pac
   }
   const bool is_heavy = e - s > heavy_from;
   if (is_heavy) {
-    if (sub == 0 && e - s > kTreeHeavyMax) heavy[atomicAdd(heavy_count, 1u)] = (u32)b;
+    if (sub == 0 && e - s > heavy_max) heavy[atomicAdd(heavy_count, 1u)] = (u32)b;
     e = s;
   }
   Xyzz acc = xyzz_identity<F>();
@@ -1924,6 +1924,13 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
     if (per_lane < 16) per_lane = 16;
     const u32 heavy_from = (u32)(per_lane * (size_t)lanes);
     const size_t tree_threads = nbt * (size_t)lanes;
+    // A bucket holds at most the entries of its window, n_total.  When that is within an eighth
+    // of kTreeHeavyMax (the IPA rounds of a 4096-bit range proof: 8194) the blocks inside the
+    // launch take every crowded bucket, nothing can be queued, and the launch for the queue is
+    // left out (about 10 us of a round's chain of launches).
+    const bool no_queue = !plan.tab && plan.n_total <= kTreeHeavyMax + kTreeHeavyMax / 8 &&
+                          nbt <= (size_t)kTreeHeavyBlocks * kTreeHeavyList;
+    const u32 heavy_max = no_queue && plan.n_total > kTreeHeavyMax ? (u32)plan.n_total : kTreeHeavyMax;
     if (nbt <= 512 && per_bucket >= 512) {
       // few buckets with many entries each (table plans on small inputs): a block per bucket
       DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3((unsigned)nbt), dim3(1024), 0, st, points,
@@ -1933,10 +1940,11 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
     DISPATCH_CURVE(curve, {
       hipLaunchKernelGGL(k_bucket_tree<C>, dim3((unsigned)((tree_threads + 255) / 256) + kTreeHeavyBlocks), dim3(256), 0,
                          st, points,
-                         ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, lanes, heavy_from, idx_mask, ws.buckets,
-                         ws.heavy, ws.heavy_count);
-      hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3(256), dim3(1024), 0, st, points, ws.vals_b,
-                         ws.bucket_start, ws.bucket_end, nbt, idx_mask, ws.buckets, ws.heavy, ws.heavy_count);
+                         ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, lanes, heavy_from, heavy_max, idx_mask,
+                         ws.buckets, ws.heavy, ws.heavy_count);
+      if (!no_queue)
+        hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3(256), dim3(1024), 0, st, points, ws.vals_b,
+                           ws.bucket_start, ws.bucket_end, nbt, idx_mask, ws.buckets, ws.heavy, ws.heavy_count);
     });
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;

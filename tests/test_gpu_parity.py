@@ -191,9 +191,29 @@ def test_msm_window_sweep(ctx, coracle, c):
     ints, K = random_scalars(c, n, 5)
     exp = coracle.msm(c.id, (px, py, None), K, 8)
     try:
-        for w in (2, 3, 5, 8, 11, 13, 16):
+        for w in (2, 3, 5, 8, 9, 10, 11, 13, 16):
             ctx.set_msm_window(w)
             assert np.array_equal(ctx.msm_unchecked(c.id, (px, py, None), K), exp), w
+    finally:
+        ctx.set_msm_window(0)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_window_reduction_equal_and_opposite_buckets(ctx, c):
+    """The same base point in neighbouring buckets: the sum tree of the window reduction meets
+    P + P (doubling inside an addition) and P + (-P) (the identity), on the one-block reduction
+    (64..256 buckets), the row/column reduction (from 512 buckets) and the segment scheme."""
+    g = c.g
+    pts = [g, g, g, g, o.scalar_mul(11, g, c)]
+    ks = [2, 3, 5, c.n - 7, 1]
+    exp = o.msm_naive(pts, ks, c)
+    assert exp == o.scalar_mul(14, g, c)
+    P, K = o.pack_points(pts, c), o.pack_field(ks, c.n)
+    try:
+        for w in (4, 7, 8, 9, 10, 12, 16):
+            ctx.set_msm_window(w)
+            xyz = ctx.msm_unchecked(c.id, P, K)
+            assert xyz_to_affine(xyz, c) == exp, w
     finally:
         ctx.set_msm_window(0)
 
