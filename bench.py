@@ -34,10 +34,10 @@ MADD_MULS = 10        # XYZZ mixed addition: 8M + 2S
 MAC_PER_MUL = 136     # 8-limb Montgomery multiply: 2*8*8 + 8 32x32 multiply-accumulates
 # Memory-side bytes of one k_chunk_sums launch at the default size, from separate
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script (averages over the
-# launches; profiles/r01_bench_msm20_v4_pmc_summary.csv).  The counters read KiB; a
+# launches; profiles/r01_bench_msm20_v7_pmc_summary.csv).  The counters read KiB; a
 # scattered read of 64-byte records with a known byte count (tools/calib_gather.py,
 # profiles/r01_gather64_calibration.csv) reads back exactly, so no factor is applied.
-PMC_TRAFFIC_2_20 = {"fetch_bytes": 1731517.2 * 1024, "write_bytes": 95412.9 * 1024}
+PMC_TRAFFIC_2_20 = {"fetch_bytes": 1746220.7 * 1024, "write_bytes": 95412.7 * 1024}
 
 
 def make_inputs(n, rank):
