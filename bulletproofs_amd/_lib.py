@@ -79,6 +79,8 @@ SIGNATURES = {
     "bp_vec_op": (ci, [vp, ci, ci, vp, vp, vp, sz, vp]),
     "bp_s_vector": (ci, [vp, ci, vp, vp, sz, vp]),
     "bp_fold_s_vectors": (ci, [vp, ci, vp, vp, vp, sz, sz, vp]),
+    "bp_range_agg_poly": (ci, [vp, ci, vp, sz, C.c_uint, vp, vp, vp, vp, vp, vp]),
+    "bp_range_agg_eval": (ci, [vp, ci, vp, sz, vp, vp, vp]),
     "bp_powers": (ci, [vp, ci, vp, sz, vp]),
     "bp_batch_inverse": (ci, [vp, ci, ci, vp, sz]),
     "bp_fold_generators": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),

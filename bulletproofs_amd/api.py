@@ -183,6 +183,29 @@ class Context:
         self._chk(lib.bp_fold_s_vectors(self.h, curve, _p(ch), _p(chi), _p(w), k, m, _p(out)))
         return out
 
+    def range_agg_poly(self, curve, values, n_bits, s_l, s_r, y, z):
+        """vector polynomials of the aggregated range proof (src/range/aggregate.rs:88-127) built on
+        the device; returns (t1, t2) and leaves l0, l1, r0, r1 in the context for range_agg_eval"""
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        sl, sr, y, z = _f(s_l), _f(s_r), _f(y), _f(z)
+        n = v.shape[0] * n_bits
+        if sl.shape[0] != n or sr.shape[0] != n:
+            raise ValueError("one blinder per bit of every value")
+        t1 = np.zeros((1, 4), dtype=np.uint64)
+        t2 = np.zeros((1, 4), dtype=np.uint64)
+        self._chk(lib.bp_range_agg_poly(self.h, curve, _p(v), v.shape[0], n_bits, _p(sl), _p(sr), _p(y), _p(z),
+                                        _p(t1), _p(t2)))
+        return t1, t2
+
+    def range_agg_eval(self, curve, x, n):
+        """l = l0 + x*l1, r = r0 + x*r1, t_hat = <l, r> (src/range/aggregate.rs:143-146)"""
+        x = _f(x)
+        l = np.zeros((n, 4), dtype=np.uint64)
+        r = np.zeros((n, 4), dtype=np.uint64)
+        t = np.zeros((1, 4), dtype=np.uint64)
+        self._chk(lib.bp_range_agg_eval(self.h, curve, _p(x), n, _p(l), _p(r), _p(t)))
+        return l, r, t
+
     def powers(self, curve, x, n):
         x = _f(x)
         out = np.zeros((n, 4), dtype=np.uint64)

@@ -23,7 +23,7 @@ enum Slot {
   S_IN0, S_IN1, S_IN2, S_IN3, S_IN4, S_IN5, S_IN6,
   S_OUT0, S_OUT1, S_OUT2,
   S_KEYS_A, S_KEYS_B, S_VALS_A, S_VALS_B, S_SORT_TMP, S_BSTART, S_BEND, S_BUCKETS, S_SEGS,
-  S_WINDOWS, S_TABLE, S_SMALL, S_NCH, S_CHOFF, S_SCAN_TMP, S_CHUNK_SUMS, S_HEAVY, S_CKEY_A, S_CKEY_B, S_CVAL_A, S_CVAL_B, S_DESC_B, S_DESC_S, S_CSORT_TMP, S_SEG_GROUPS, S_PACKED, S_COUNT
+  S_WINDOWS, S_TABLE, S_SMALL, S_NCH, S_CHOFF, S_SCAN_TMP, S_CHUNK_SUMS, S_HEAVY, S_CKEY_A, S_CKEY_B, S_CVAL_A, S_CVAL_B, S_DESC_B, S_DESC_S, S_CSORT_TMP, S_SEG_GROUPS, S_PACKED, S_RANGE, S_COUNT
 };
 
 struct DevBuf {
@@ -99,6 +99,9 @@ struct bp_ctx {
   MsmPipe pipe;         // second and third stream of large MSMs
   int last_stages = 1;  // batches of the last MSM (its accumulation time is the sum over pipe.cs0/cs1)
   HostWorker worker;
+  // vector polynomials left on the device by bp_range_agg_poly for bp_range_agg_eval (S_RANGE)
+  size_t range_n = 0;
+  int range_curve = -1;
 };
 
 struct bp_bases {
@@ -237,6 +240,22 @@ FeArg to_canonical_fr(int curve, const uint64_t v[4]) {
   FeArg a;
   memcpy(a.v, c.v, 32);
   return a;
+}
+
+// zpow[j] = z^(2+j), j < m; pow2[i] = 2^i, i < n_bits (Montgomery form, 4 u64 each)
+template <class Fr>
+void range_tables(const uint64_t z[4], size_t m, unsigned n_bits, uint64_t* zpow, uint64_t* pow2) {
+  host::HFe zz, zp, p2 = host::h_one<Fr>();
+  memcpy(zz.v, z, 32);
+  zp = host::h_mul<Fr>(zz, zz);
+  for (size_t j = 0; j < m; j++) {
+    memcpy(zpow + 4 * j, zp.v, 32);
+    zp = host::h_mul<Fr>(zp, zz);
+  }
+  for (unsigned i = 0; i < n_bits; i++) {
+    memcpy(pow2 + 4 * i, p2.v, 32);
+    p2 = host::h_dbl<Fr>(p2);
+  }
 }
 
 void finish_windows(int curve, const uint64_t* win, int n_windows, int c, uint64_t out_xyz[12]) {
@@ -766,6 +785,69 @@ int bp_powers(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* o
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "powers", e);
   HIPCHK(ctx, hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_range_agg_poly(bp_ctx* ctx, int curve, const uint64_t* values, size_t m, unsigned n_bits, const uint64_t* s_l,
+                      const uint64_t* s_r, const uint64_t y[4], const uint64_t z[4], uint64_t t1[4], uint64_t t2[4]) {
+  if (!ctx || !values || !s_l || !s_r || !y || !z || !t1 || !t2) return fail(ctx, BP_E_ARG, "bp_range_agg_poly: null argument");
+  if (m == 0 || n_bits == 0 || n_bits > 64 || m > ((size_t)1 << 24)) return fail(ctx, BP_E_ARG, "bp_range_agg_poly: bad size");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  const size_t n = m * n_bits, blocks = (n + 255) / 256;
+  ctx->range_n = 0;
+  std::vector<uint64_t> tab(4 * (m + n_bits));
+  if (curve == BP_SECP256K1)
+    range_tables<Secp256k1Fr>(z, m, n_bits, tab.data(), tab.data() + 4 * m);
+  else
+    range_tables<VestaFr>(z, m, n_bits, tab.data(), tab.data() + 4 * m);
+  void *dval, *dtab, *dsr, *dyv, *dpt, *dpart, *drange;
+  CHK(upload(ctx, S_IN0, values, m * 8, &dval));
+  CHK(upload(ctx, S_IN1, tab.data(), tab.size() * 8, &dtab));
+  CHK(upload(ctx, S_IN2, s_r, n * 32, &dsr));
+  CHK(reserve(ctx, S_RANGE, 6 * n * 32, &drange));
+  u32 *l0 = (u32*)drange, *r0 = l0 + n * 8, *r1 = r0 + n * 8, *l1 = r1 + n * 8;
+  HIPCHK(ctx, hipMemcpyAsync(l1, s_l, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  CHK(reserve(ctx, S_TABLE, powers_table_elems(n) * 32, &dpt));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dyv));
+  CHK(reserve(ctx, S_SMALL, (3 * blocks + 2) * 32, &dpart));
+  hipError_t e = launch_powers(curve, to_arg(y), n, (u32*)dpt, (u32*)dyv, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "powers", e);
+  u32* dout = (u32*)dpart + 3 * blocks * 8;
+  e = launch_range_poly(curve, (const uint64_t*)dval, n_bits, n, (const u32*)dtab, (const u32*)dtab + 8 * m,
+                        (const u32*)dyv, l1, (const u32*)dsr, to_arg(z), l0, r0, r1, (u32*)dpart, dout, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "range_poly", e);
+  CHK(reserve_pinned(ctx, 64));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, dout, 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(t1, ctx->pinned, 32);
+  memcpy(t2, (char*)ctx->pinned + 32, 32);
+  ctx->range_n = n;
+  ctx->range_curve = curve;
+  return BP_OK;
+}
+
+int bp_range_agg_eval(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* l, uint64_t* r,
+                      uint64_t t_hat[4]) {
+  if (!ctx || !x || !l || !r || !t_hat) return fail(ctx, BP_E_ARG, "bp_range_agg_eval: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0 || ctx->range_n != n || ctx->range_curve != curve)
+    return fail(ctx, BP_E_STATE, "bp_range_agg_eval: no vector polynomials of this size (call bp_range_agg_poly first)");
+  const size_t blocks = (n + 255) / 256;
+  void *drange, *dpart;
+  CHK(reserve(ctx, S_RANGE, 6 * n * 32, &drange));
+  CHK(reserve(ctx, S_SMALL, (blocks + 1) * 32, &dpart));
+  u32 *l0 = (u32*)drange, *r0 = l0 + n * 8, *r1 = r0 + n * 8, *l1 = r1 + n * 8, *dl = l1 + n * 8, *dr = dl + n * 8;
+  u32* dout = (u32*)dpart + blocks * 8;
+  hipError_t e = launch_range_eval(curve, l0, l1, r0, r1, n, to_arg(x), dl, dr, (u32*)dpart, dout, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "range_eval", e);
+  CHK(reserve_pinned(ctx, 32));
+  HIPCHK(ctx, hipMemcpyAsync(l, dl, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(r, dr, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, dout, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(t_hat, ctx->pinned, 32);
   return BP_OK;
 }
 

@@ -43,6 +43,15 @@ hipError_t launch_batch_inverse(int curve, int field, u32* v, size_t n, hipStrea
 // whose current length is 2*half.
 hipError_t launch_ipa_coef_update(int curve, u32* cg, u32* ch, size_t n0, size_t half, FeArg x, FeArg x_inv,
                                   hipStream_t st);
+// vector polynomials of the aggregated range proof (src/range/aggregate.rs:93-127): l0, r0, r1 from
+// the bits of `values` (m = n / n_bits of them), zpow[j] = z^(2+j), pow2[i] = 2^i, yv[k] = y^k and
+// the blinders; out[0] = t1, out[1] = t2.  partials: >= 3 * ceil(n/256) elements.
+hipError_t launch_range_poly(int curve, const uint64_t* values, unsigned n_bits, size_t n, const u32* zpow,
+                             const u32* pow2, const u32* yv, const u32* s_l, const u32* s_r, FeArg z, u32* l0, u32* r0,
+                             u32* r1, u32* partials, u32* out, hipStream_t st);
+// l = l0 + x*l1, r = r0 + x*r1, out = <l, r> (:143-146).  partials: >= ceil(n/256) elements.
+hipError_t launch_range_eval(int curve, const u32* l0, const u32* l1, const u32* r0, const u32* r1, size_t n, FeArg x,
+                             u32* l, u32* r, u32* partials, u32* out, hipStream_t st);
 // coefficient update and both scalar folds of a round in one launch (a, b folded in place)
 hipError_t launch_ipa_round_fold(int curve, u32* a, u32* b, u32* cg, u32* ch, size_t n0, size_t half, FeArg x,
                                  FeArg x_inv, hipStream_t st);

@@ -362,6 +362,112 @@ hipError_t launch_batch_inverse(int curve, int field, u32* v, size_t n, hipStrea
   return hipGetLastError();
 }
 
+// ---- vector polynomials of the aggregated range proof ------------------------------
+// src/range/aggregate.rs:50-64 and :93-127.  Element k = j*n_bits + i (value j, bit i):
+//   a_L = bit, a_R = bit - 1
+//   l0 = a_L - z,  r0 = y^k (a_R + z) + z^(2+j) 2^i,  r1 = y^k s_R   (l1 = s_L)
+// and the three inner products behind t1 = <l0, r1> + <l1, r0>, t2 = <l1, r1>
+// (src/range/types.rs:98-117) as one partial sum each per block.
+template <class F>
+__global__ __launch_bounds__(256) void k_range_poly(const uint64_t* __restrict__ values, unsigned n_bits, size_t n,
+                                                    const u32* __restrict__ zpow, const u32* __restrict__ pow2,
+                                                    const u32* __restrict__ yv, const u32* __restrict__ s_l,
+                                                    const u32* __restrict__ s_r, FeArg za, u32* __restrict__ l0,
+                                                    u32* __restrict__ r0, u32* __restrict__ r1,
+                                                    u32* __restrict__ partials) {
+  __shared__ u32 lds[3 * 32];
+  const Fe z = arg_to_fe(za), one = fe_one<F>();
+  Fe d0 = fe_zero(), d1 = fe_zero(), d2 = fe_zero();
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    const size_t j = k / n_bits;
+    const unsigned i = (unsigned)(k % n_bits);
+    const bool bit = (values[j] >> i) & 1;
+    const Fe al = bit ? one : fe_zero();
+    const Fe ar = bit ? fe_zero() : fe_neg<F>(one);
+    const Fe yk = fe_load(yv + k * 8), sl = fe_load(s_l + k * 8), sr = fe_load(s_r + k * 8);
+    const Fe vl0 = fe_sub<F>(al, z);
+    const Fe vr0 = fe_add<F>(fe_mul<F>(yk, fe_add<F>(ar, z)), fe_mul<F>(fe_load(zpow + j * 8), fe_load(pow2 + i * 8)));
+    const Fe vr1 = fe_mul<F>(yk, sr);
+    fe_store(l0 + k * 8, vl0);
+    fe_store(r0 + k * 8, vr0);
+    fe_store(r1 + k * 8, vr1);
+    d0 = fe_mul<F>(vl0, vr1);
+    d1 = fe_mul<F>(sl, vr0);
+    d2 = fe_mul<F>(sl, vr1);
+  }
+  Fe t0 = block_reduce_add<F>(d0, lds);
+  Fe t1 = block_reduce_add<F>(d1, lds + 32);
+  Fe t2 = block_reduce_add<F>(d2, lds + 64);
+  if (threadIdx.x == 0) {
+    fe_store(partials + ((size_t)blockIdx.x * 3 + 0) * 8, t0);
+    fe_store(partials + ((size_t)blockIdx.x * 3 + 1) * 8, t1);
+    fe_store(partials + ((size_t)blockIdx.x * 3 + 2) * 8, t2);
+  }
+}
+
+// out[0] = t1 = sum of the first two partial sums of every block, out[1] = t2 = sum of the third
+template <class F>
+__global__ __launch_bounds__(256) void k_range_poly_final(const u32* __restrict__ partials, int blocks,
+                                                          u32* __restrict__ out) {
+  __shared__ u32 lds[2 * 32];
+  Fe a = fe_zero(), b = fe_zero();
+  for (int i = threadIdx.x; i < blocks; i += blockDim.x) {
+    a = fe_add<F>(a, fe_add<F>(fe_load(partials + ((size_t)i * 3 + 0) * 8), fe_load(partials + ((size_t)i * 3 + 1) * 8)));
+    b = fe_add<F>(b, fe_load(partials + ((size_t)i * 3 + 2) * 8));
+  }
+  Fe ta = block_reduce_add<F>(a, lds);
+  Fe tb = block_reduce_add<F>(b, lds + 32);
+  if (threadIdx.x == 0) {
+    fe_store(out, ta);
+    fe_store(out + 8, tb);
+  }
+}
+
+// src/range/aggregate.rs:143-146: l = l0 + x l1, r = r0 + x r1 (VectorPolynomial::evaluate,
+// src/range/types.rs:119-129) and the partial sums of t_hat = <l, r>
+template <class F>
+__global__ __launch_bounds__(256) void k_range_eval(const u32* __restrict__ l0, const u32* __restrict__ l1,
+                                                    const u32* __restrict__ r0, const u32* __restrict__ r1, size_t n,
+                                                    FeArg xa, u32* __restrict__ l, u32* __restrict__ r,
+                                                    u32* __restrict__ partials) {
+  __shared__ u32 lds[32];
+  const Fe x = arg_to_fe(xa);
+  Fe d = fe_zero();
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    const Fe vl = fe_add<F>(fe_load(l0 + k * 8), fe_mul<F>(x, fe_load(l1 + k * 8)));
+    const Fe vr = fe_add<F>(fe_load(r0 + k * 8), fe_mul<F>(x, fe_load(r1 + k * 8)));
+    fe_store(l + k * 8, vl);
+    fe_store(r + k * 8, vr);
+    d = fe_mul<F>(vl, vr);
+  }
+  Fe t = block_reduce_add<F>(d, lds);
+  if (threadIdx.x == 0) fe_store(partials + (size_t)blockIdx.x * 8, t);
+}
+
+hipError_t launch_range_poly(int curve, const uint64_t* values, unsigned n_bits, size_t n, const u32* zpow,
+                             const u32* pow2, const u32* yv, const u32* s_l, const u32* s_r, FeArg z, u32* l0, u32* r0,
+                             u32* r1, u32* partials, u32* out, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  DISPATCH_FR(curve, {
+    hipLaunchKernelGGL(k_range_poly<F>, dim3(blocks), dim3(256), 0, st, values, n_bits, n, zpow, pow2, yv, s_l, s_r, z, l0,
+                       r0, r1, partials);
+    hipLaunchKernelGGL(k_range_poly_final<F>, dim3(1), dim3(256), 0, st, partials, (int)blocks, out);
+  });
+  return hipGetLastError();
+}
+
+hipError_t launch_range_eval(int curve, const u32* l0, const u32* l1, const u32* r0, const u32* r1, size_t n, FeArg x,
+                             u32* l, u32* r, u32* partials, u32* out, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  DISPATCH_FR(curve, {
+    hipLaunchKernelGGL(k_range_eval<F>, dim3(blocks), dim3(256), 0, st, l0, l1, r0, r1, n, x, l, r, partials);
+    hipLaunchKernelGGL(k_dot_final<F>, dim3(1), dim3(256), 0, st, partials, (int)blocks, out);
+  });
+  return hipGetLastError();
+}
+
 // ---- IPA rounds over unfolded generators ----------------------------------------
 // After j rounds the folded generator G_i (i < n_j = n0 / 2^j) of src/ipa/mod.rs:80-83 is
 //   G_i = sum_{k = i mod n_j} cg[k] * G0_k,   cg[k] = prod_t (k in the upper half at round t ? x_t : x_t^-1)

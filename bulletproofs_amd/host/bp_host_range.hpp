@@ -110,26 +110,15 @@ struct RangeAggregate {
     Projective as[2] = {pr.a, pr.s};
     t.prover_points(as, 2);                                  // :85
     Scalar y = t.verifier_scalar(), z = t.verifier_scalar(); // :86
-    std::vector<Scalar> y_vec(n);
-    check(ctx, bp_powers(ctx, CURVE, y.l, n, y_vec[0].l), "bp_powers");  // :88-91
-    // l(X) = (a_L - z) + s_L X ; r(X) = y^n o (a_R + z) + z^(2+j) 2^i + (y^n o s_R) X   (:93-119)
-    std::vector<Scalar> l0(n), r0(n), r1(n);
-    Scalar two = from_u64(2), zz = S::mul(z, z), zpow = zz;
-    for (size_t j = 0; j < m; j++) {
-      Scalar pow2 = one;
-      for (unsigned i = 0; i < n_bits; i++) {
-        size_t k = j * n_bits + i;
-        l0[k] = sub(a_l[k], z);
-        r0[k] = S::add(S::mul(y_vec[k], S::add(a_r[k], z)), S::mul(zpow, pow2));
-        r1[k] = S::mul(y_vec[k], s_r[k]);
-        pow2 = S::mul(pow2, two);
-      }
-      zpow = S::mul(zpow, z);
-    }
+    // :88-127 -- y^n, l(X) = (a_L - z) + s_L X, r(X) = y^n o (a_R + z) + z^(2+j) 2^i + (y^n o s_R) X and
+    // t1 = <l0,r1> + <l1,r0>, t2 = <l1,r1> (src/range/types.rs:98-117) are built on the device from
+    // the values and the blinders; the vectors stay there for the evaluation at x
+    Scalar zz = S::mul(z, z), zpow = zz;
+    Scalar t1, t2;
+    check(ctx, bp_range_agg_poly(ctx, CURVE, values.data(), m, n_bits, s_l[0].l, s_r[0].l, y.l, z.l, t1.l, t2.l),
+          "bp_range_agg_poly");
     tr.mark("powers, l/r polynomials");
     Scalar tao1 = rng.scalar(), tao2 = rng.scalar();         // :121-122
-    // t(X) = <l(X), r(X)>: t1 = <l0,r1> + <l1,r0>, t2 = <l1,r1>   (:125, src/range/types.rs:98-117)
-    Scalar t1 = S::add(dot(ctx, l0, r1), dot(ctx, s_l, r0)), t2 = dot(ctx, s_l, r1);
     pr.tt1 = P::lower(hx_add<Fq>(crs.g_tab.mul(t1), crs.h_tab.mul(tao1)));  // :126
     pr.tt2 = P::lower(hx_add<Fq>(crs.g_tab.mul(t2), crs.h_tab.mul(tao2)));  // :127
     tr.mark("t1, t2, T1, T2");
@@ -141,10 +130,8 @@ struct RangeAggregate {
     for (size_t j = 0; j < m; j++) { sigma = S::add(sigma, S::mul(zpow, gamma[j])); zpow = S::mul(zpow, z); }
     pr.tao_x = S::add(S::add(S::mul(tao1, x), S::mul(tao2, S::mul(x, x))), sigma);  // :140
     pr.mu = S::add(alpha, S::mul(rho, x));                   // :142
-    std::vector<Scalar> l(n), r(n);                          // :143-144
-    check(ctx, bp_vec_op(ctx, CURVE, BP_VEC_AXPY, l0[0].l, s_l[0].l, x.l, n, l[0].l), "axpy");
-    check(ctx, bp_vec_op(ctx, CURVE, BP_VEC_AXPY, r0[0].l, r1[0].l, x.l, n, r[0].l), "axpy");
-    pr.t_hat = dot(ctx, l, r);                               // Witness::new, :146
+    std::vector<Scalar> l(n), r(n);                          // :143-144, Witness::new :146
+    check(ctx, bp_range_agg_eval(ctx, CURVE, x.l, n, l[0].l, r[0].l, pr.t_hat.l), "bp_range_agg_eval");
     // :148-153 -- hs'_i = y^-i h_i is not materialised (N scalar multiplications in the
     // reference): the IPA session over the resident gs || hs carries y^-i as the initial
     // coefficient of h_i, which yields the same L, R, a, b.

@@ -159,6 +159,21 @@ int bp_s_vector(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_i
  * scalars, weights: m scalars, m >= 1. */
 int bp_fold_s_vectors(bp_ctx* ctx, int curve, const uint64_t* ch, const uint64_t* ch_inv,
                       const uint64_t* weights, size_t k, size_t m, uint64_t* out);
+/* Vector polynomials of the aggregated range proof, src/range/aggregate.rs:50-64 and :88-127, built
+ * on the device from the m values (bits taken low to high, n_bits <= 64 each; n = m * n_bits), the
+ * blinders s_l, s_r (n scalars each) and the challenges y, z:
+ *   l0 = a_L - z,  l1 = s_L,  r0 = y^k o (a_R + z) + z^(2+j) 2^i,  r1 = y^k o s_R
+ * with a_L the bits and a_R = a_L - 1.  Returns t1 = <l0, r1> + <l1, r0> and t2 = <l1, r1>
+ * (VectorPolynomial::inner_product, src/range/types.rs:98-117); the four vectors stay in the
+ * context for bp_range_agg_eval. */
+int bp_range_agg_poly(bp_ctx* ctx, int curve, const uint64_t* values, size_t m, unsigned n_bits,
+                      const uint64_t* s_l, const uint64_t* s_r, const uint64_t y[4], const uint64_t z[4],
+                      uint64_t t1[4], uint64_t t2[4]);
+/* l = l0 + x l1, r = r0 + x r1 (VectorPolynomial::evaluate, src/range/types.rs:119-129, as called
+ * at src/range/aggregate.rs:143-144) and t_hat = <l, r> (:146), from the vectors the last
+ * bp_range_agg_poly of this context left; n must be that call's m * n_bits (BP_E_STATE otherwise). */
+int bp_range_agg_eval(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* l, uint64_t* r,
+                      uint64_t t_hat[4]);
 /* out[i] = x^i, i < n: powers_of_x src/poly_commit/mod.rs:16-22, y_vec
  * src/range/aggregate.rs:88-91, hs' scalars src/range/utils.rs:22-29. */
 int bp_powers(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* out);

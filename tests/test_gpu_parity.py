@@ -150,6 +150,47 @@ def test_fold_s_vectors(ctx, c, k, m):
         assert o.unpack_field(got, c.n) == exp
 
 
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("m,n_bits", [(1, 8), (3, 5), (2, 64), (64, 64), (5, 33)])
+def test_range_agg_vector_polynomials(ctx, c, m, n_bits):
+    """l(X), r(X), t1, t2, then l, r, t_hat of the aggregated range proof
+    (src/range/aggregate.rs:50-64, 88-127, 143-146; src/range/types.rs:98-129) against the
+    big-integer restatement; includes the all-zero and all-ones values."""
+    rng = o.SplitMix64(0xA66 + 64 * m + n_bits)
+    mask = (1 << n_bits) - 1
+    values = [rng.next() & mask for _ in range(m)]
+    values[0] = mask
+    if m > 1:
+        values[1] = 0
+    n = m * n_bits
+    sl, sr = rng.scalars(n, c.n), rng.scalars(n, c.n)
+    y, z, x = rng.field(c.n), rng.field(c.n), rng.field(c.n)
+    l0, r0, r1 = [], [], []
+    for j in range(m):
+        for i in range(n_bits):
+            k = j * n_bits + i
+            bit = (values[j] >> i) & 1
+            l0.append((bit - z) % c.n)
+            r0.append((pow(y, k, c.n) * ((bit - 1) + z) + pow(z, 2 + j, c.n) * (1 << i)) % c.n)
+            r1.append(pow(y, k, c.n) * sr[k] % c.n)
+    dot = lambda a, b: sum(u * v for u, v in zip(a, b)) % c.n  # noqa: E731
+    f = lambda v: o.pack_field(v, c.n)  # noqa: E731
+    t1, t2 = ctx.range_agg_poly(c.id, np.array(values, dtype=np.uint64), n_bits, f(sl), f(sr), f([y]), f([z]))
+    assert o.unpack_field(t1, c.n) == [(dot(l0, r1) + dot(sl, r0)) % c.n]
+    assert o.unpack_field(t2, c.n) == [dot(sl, r1)]
+    l, r, t_hat = ctx.range_agg_eval(c.id, f([x]), n)
+    el = [(a + x * b) % c.n for a, b in zip(l0, sl)]
+    er = [(a + x * b) % c.n for a, b in zip(r0, r1)]
+    assert o.unpack_field(l, c.n) == el and o.unpack_field(r, c.n) == er
+    assert o.unpack_field(t_hat, c.n) == [dot(el, er)]
+    # t(x) = t0 + t1 x + t2 x^2 with t0 = <l0, r0> (the identity the verifier relies on)
+    t1i, t2i = o.unpack_field(t1, c.n)[0], o.unpack_field(t2, c.n)[0]
+    assert (dot(l0, r0) + t1i * x + t2i * x * x) % c.n == dot(el, er)
+    # a second evaluation of another size is a state error
+    with pytest.raises(Exception):
+        ctx.range_agg_eval(c.id, f([x]), n + 1)
+
+
 # ---- MSM ----------------------------------------------------------------------------
 
 
