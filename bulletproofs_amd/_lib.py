@@ -71,6 +71,7 @@ SIGNATURES = {
     "bp_bases_free": (None, [vp]),
     "bp_bases_len": (sz, [vp]),
     "bp_msm_resident": (ci, [vp, vp, sz, sz, vp, vp]),
+    "bp_msm_resident_pair": (ci, [vp, vp, sz, sz, vp, vp, vp, vp]),
     "bp_msm_windows_dev": (ci, [vp, ci, vp, vp, vp, vp, sz, vp, C.POINTER(ci), C.POINTER(ci)]),
     "bp_msm_combine_windows_dev": (ci, [vp, ci, vp, ci, ci, ci, vp]),
     "bp_inner_product": (ci, [vp, ci, vp, vp, sz, vp]),

@@ -293,6 +293,18 @@ class Bases:
         self.ctx._chk(lib.bp_msm_resident(self.ctx.h, self.h, offset, n, _p(s), _p(out)))
         return out
 
+    def msm_pair(self, scalars_a, scalars_b, offset=0, n=None):
+        """two sums over the same points in one pass (the A and S commitments of the range proofs)"""
+        a, b = _f(scalars_a), _f(scalars_b)
+        if n is None:
+            n = min(a.shape[0], b.shape[0])
+        if a.shape[0] < n or b.shape[0] < n:
+            raise ValueError("fewer scalars than points")
+        oa = np.zeros(12, dtype=np.uint64)
+        ob = np.zeros(12, dtype=np.uint64)
+        self.ctx._chk(lib.bp_msm_resident_pair(self.ctx.h, self.h, offset, n, _p(a), _p(b), _p(oa), _p(ob)))
+        return oa, ob
+
     def free(self):
         if self.h:
             lib.bp_bases_free(self.h)

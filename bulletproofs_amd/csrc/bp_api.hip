@@ -559,6 +559,39 @@ int bp_msm_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
   return msm_full(ctx, bases->curve, p0, p1, out_xyz, bases->tab && n <= kTableMaxPoints ? &table : nullptr);
 }
 
+int bp_msm_resident_pair(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n, const uint64_t* scalars_a,
+                         const uint64_t* scalars_b, uint64_t out_a_xyz[12], uint64_t out_b_xyz[12]) {
+  if (!ctx || !bases || !out_a_xyz || !out_b_xyz || (n && (!scalars_a || !scalars_b)))
+    return fail(ctx, BP_E_ARG, "bp_msm_resident_pair: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_msm_resident_pair: bases belong to another context");
+  if (offset > bases->n || n > bases->n - offset) return fail(ctx, BP_E_ARG, "bp_msm_resident_pair: range outside bases");
+  Guard g(ctx);
+  void *da, *db;
+  CHK(upload(ctx, S_IN3, scalars_a, n * 32, &da));
+  CHK(upload(ctx, S_IN4, scalars_b, n * 32, &db));
+  // one pass, two sums: the points once with each scalar vector, as groups 0 and 1
+  MsmPart p0{bases->x + offset * 8, bases->y + offset * 8, bases->inf + offset, (const u32*)da, n};
+  MsmPart p1{bases->x + offset * 8, bases->y + offset * 8, bases->inf + offset, (const u32*)db, n};
+  p1.group_lo = p1.group_hi = 1;
+  MsmPlan plan;
+  u32* d_win = nullptr;
+  CHK(msm_device(ctx, bases->curve, p0, p1, &plan, &d_win, 2));
+  CHK(reserve_pinned(ctx, plan.win_bytes));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  msm_collect_times(ctx, plan.n_total != 0);
+  const int curve = bases->curve, gw = plan.group_windows, c = plan.c;
+  const uint64_t* win = (const uint64_t*)ctx->pinned;
+  const uint64_t* win_b = win + (size_t)gw * 16;
+  const bool helped = ctx->worker.submit([=] { finish_windows(curve, win_b, gw, c, out_b_xyz); });
+  finish_windows(curve, win, gw, c, out_a_xyz);
+  if (helped)
+    ctx->worker.wait();
+  else
+    finish_windows(curve, win_b, gw, c, out_b_xyz);
+  return BP_OK;
+}
+
 int bp_msm_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64_t* d_y, const uint8_t* d_inf,
                        const uint64_t* d_scalars, size_t n, uint64_t* d_windows, int* n_windows,
                        int* window_bits) {

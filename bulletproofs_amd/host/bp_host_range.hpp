@@ -104,8 +104,16 @@ struct RangeAggregate {
     for (auto& v : s_r) v = rng.scalar();
     RangeProof pr;
     tr.mark("bits, blinders");
-    pr.a = P::lower(hx_add<Fq>(crs.h_tab.mul(alpha), P::lift(msm_gh(ctx, crs, a_l, a_r))));   // :81
-    pr.s = P::lower(hx_add<Fq>(crs.h_tab.mul(rho), P::lift(msm_gh(ctx, crs, s_l, s_r))));     // :82
+    // :80-83 -- the two MSMs of rayon::join as one pass with two sums over gs || hs
+    Projective a_msm, s_msm;
+    {
+      std::vector<Scalar> sa(a_l), ss(s_l);
+      sa.insert(sa.end(), a_r.begin(), a_r.end());
+      ss.insert(ss.end(), s_r.begin(), s_r.end());
+      check(ctx, bp_msm_resident_pair(ctx, crs.gh, 0, 2 * n, sa[0].l, ss[0].l, a_msm.xyz, s_msm.xyz), "bp_msm_resident_pair");
+    }
+    pr.a = P::lower(hx_add<Fq>(crs.h_tab.mul(alpha), P::lift(a_msm)));   // :81
+    pr.s = P::lower(hx_add<Fq>(crs.h_tab.mul(rho), P::lift(s_msm)));     // :82
     tr.mark("A, S commitments");
     Projective as[2] = {pr.a, pr.s};
     t.prover_points(as, 2);                                  // :85

@@ -115,6 +115,13 @@ int bp_bases_precompute(bp_bases* b);
  * src/ipa/types.rs:81-82). */
 int bp_msm_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
                     const uint64_t* scalars, uint64_t out_xyz[12]);
+/* Two sums over the same n registered points in one pass: out_a = sum scalars_a[i] * P_i,
+ * out_b = sum scalars_b[i] * P_i.  The A and S commitments of the range proofs, which the
+ * reference computes side by side under rayon::join (src/range/aggregate.rs:80-83,
+ * src/range/mod.rs:76-79), are one launch sequence instead of two. */
+int bp_msm_resident_pair(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
+                         const uint64_t* scalars_a, const uint64_t* scalars_b, uint64_t out_a_xyz[12],
+                         uint64_t out_b_xyz[12]);
 /* MSM over bases[offset .. offset+2^k) with the s-vector of k challenges as scalars,
  * built on the device and never copied: `G::msm_unchecked(&crs.gs, &h_poly.coeffs())`
  * (src/poly_commit/mod.rs:109-111,152-159).  ch_inv[j] = ch[j]^-1; k <= 28. */

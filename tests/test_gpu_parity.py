@@ -418,6 +418,24 @@ def test_msm_resident_and_two_part(ctx, coracle, c):
         assert np.array_equal(bases.msm(K[:cnt], off, cnt), exp), (off, cnt)
     with pytest.raises(Exception):
         bases.msm(K[:10], n - 5, 10)
+    # two sums over the same points in one pass (A and S of the range proofs: one vector of
+    # {0, 1, -1}, one uniform), at sizes on either side of the one-launch front end
+    _, K2 = random_scalars(c, n, 10)
+    deg = o.pack_field([(0, 1, c.n - 1)[i % 3] for i in range(n)], c.n)
+    for off, cnt, A, B in ((0, n, K, K2), (50, 2048, deg, K2), (0, 1, K, K2), (3, 0, K, K2)):
+        pts = (px[off:off + cnt], py[off:off + cnt], inf[off:off + cnt])
+        ga, gb = bases.msm_pair(A[:cnt], B[:cnt], off, cnt)
+        assert np.array_equal(ga, coracle.msm(c.id, pts, A[:cnt], 4)), (off, cnt)
+        assert np.array_equal(gb, coracle.msm(c.id, pts, B[:cnt], 4)), (off, cnt)
+    bases.free()
+    big = 12000  # 2 x 12000 points: beyond the one-launch front end
+    bx, by = seeded_points(coracle, c, big, 5, 3)
+    _, KA = random_scalars(c, big, 21)
+    _, KB = random_scalars(c, big, 22)
+    bases = ctx.register_bases(c.id, (bx, by, None))
+    ga, gb = bases.msm_pair(KA, KB)
+    assert np.array_equal(ga, coracle.msm(c.id, (bx, by, None), KA, 8))
+    assert np.array_equal(gb, coracle.msm(c.id, (bx, by, None), KB, 8))
     bases.free()
     # two-part form = concatenated form (src/ipa/mod.rs:44-54)
     dx, dy, dk = _dev(px), _dev(py), _dev(K)
