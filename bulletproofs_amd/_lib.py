@@ -72,6 +72,7 @@ SIGNATURES = {
     "bp_bases_len": (sz, [vp]),
     "bp_msm_resident": (ci, [vp, vp, sz, sz, vp, vp]),
     "bp_msm_resident_pair": (ci, [vp, vp, sz, sz, vp, vp, vp, vp]),
+    "bp_msm_resident_plus": (ci, [vp, vp, sz, sz, vp, vp, vp, vp, vp, sz, vp]),
     "bp_msm_windows_dev": (ci, [vp, ci, vp, vp, vp, vp, sz, vp, C.POINTER(ci), C.POINTER(ci)]),
     "bp_msm_combine_windows_dev": (ci, [vp, ci, vp, ci, ci, ci, vp]),
     "bp_inner_product": (ci, [vp, ci, vp, vp, sz, vp]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "bp_fold_s_vectors": (ci, [vp, ci, vp, vp, vp, sz, sz, vp]),
     "bp_range_agg_poly": (ci, [vp, ci, vp, sz, C.c_uint, vp, vp, vp, vp, vp, vp]),
     "bp_range_agg_eval": (ci, [vp, ci, vp, sz, vp, vp, vp]),
+    "bp_range_agg_verify_scalars": (ci, [vp, ci, vp, vp, sz, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
     "bp_powers": (ci, [vp, ci, vp, sz, vp]),
     "bp_batch_inverse": (ci, [vp, ci, ci, vp, sz]),
     "bp_fold_generators": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),

@@ -206,6 +206,17 @@ class Context:
         self._chk(lib.bp_range_agg_eval(self.h, curve, _p(x), n, _p(l), _p(r), _p(t)))
         return l, r, t
 
+    def range_agg_verify_scalars(self, curve, challenges, challenge_inverses, a, b, y_inv, z, m, n_bits):
+        """scalars of gs_i and hs_i in the verifier's single deferred MSM (see bp_gpu.h)"""
+        ch, chi = _f(challenges), _f(challenge_inverses)
+        k = ch.shape[0]
+        n = 1 << k
+        og = np.zeros((n, 4), dtype=np.uint64)
+        oh = np.zeros((n, 4), dtype=np.uint64)
+        self._chk(lib.bp_range_agg_verify_scalars(self.h, curve, _p(ch), _p(chi), k, _p(_f(a)), _p(_f(b)), _p(_f(y_inv)),
+                                                  _p(_f(z)), m, n_bits, _p(og), _p(oh)))
+        return og, oh
+
     def powers(self, curve, x, n):
         x = _f(x)
         out = np.zeros((n, 4), dtype=np.uint64)
@@ -291,6 +302,19 @@ class Bases:
             n = s.shape[0]
         out = np.zeros(12, dtype=np.uint64)
         self.ctx._chk(lib.bp_msm_resident(self.ctx.h, self.h, offset, n, _p(s), _p(out)))
+        return out
+
+    def msm_plus(self, scalars, extra_points, extra_scalars, offset=0, n=None):
+        """sum over registered points plus a few uploaded ones (a verifier's deferred MSM)"""
+        s = _f(scalars)
+        if n is None:
+            n = s.shape[0]
+        ex, ey, einf = _pts(extra_points)
+        es = _f(extra_scalars)
+        k = min(ex.shape[0], es.shape[0])
+        out = np.zeros(12, dtype=np.uint64)
+        self.ctx._chk(lib.bp_msm_resident_plus(self.ctx.h, self.h, offset, n, _p(s), _p(ex), _p(ey), _p(einf), _p(es), k,
+                                               _p(out)))
         return out
 
     def msm_pair(self, scalars_a, scalars_b, offset=0, n=None):

@@ -14,6 +14,7 @@
 
 #include "bp_host_math.h"
 #include "bp_internal.h"
+#include "bp_range.h"
 
 using namespace bp;
 
@@ -592,6 +593,27 @@ int bp_msm_resident_pair(bp_ctx* ctx, const bp_bases* bases, size_t offset, size
   return BP_OK;
 }
 
+int bp_msm_resident_plus(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n, const uint64_t* scalars,
+                         const uint64_t* extra_x, const uint64_t* extra_y, const uint8_t* extra_inf,
+                         const uint64_t* extra_scalars, size_t n_extra, uint64_t out_xyz[12]) {
+  if (!ctx || !bases || !out_xyz || (n && !scalars) || (n_extra && (!extra_x || !extra_y || !extra_scalars)))
+    return fail(ctx, BP_E_ARG, "bp_msm_resident_plus: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_msm_resident_plus: bases belong to another context");
+  if (offset > bases->n || n > bases->n - offset) return fail(ctx, BP_E_ARG, "bp_msm_resident_plus: range outside bases");
+  Guard g(ctx);
+  void *ds, *dx = nullptr, *dy = nullptr, *di = nullptr, *des = nullptr;
+  CHK(upload(ctx, S_IN3, scalars, n * 32, &ds));
+  if (n_extra) {
+    CHK(upload(ctx, S_IN0, extra_x, n_extra * 32, &dx));
+    CHK(upload(ctx, S_IN1, extra_y, n_extra * 32, &dy));
+    if (extra_inf) CHK(upload(ctx, S_IN2, extra_inf, n_extra, &di));
+    CHK(upload(ctx, S_IN4, extra_scalars, n_extra * 32, &des));
+  }
+  MsmPart p0{bases->x + offset * 8, bases->y + offset * 8, bases->inf + offset, (const u32*)ds, n};
+  MsmPart p1{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)des, n_extra};
+  return msm_full(ctx, bases->curve, p0, p1, out_xyz);
+}
+
 int bp_msm_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64_t* d_y, const uint8_t* d_inf,
                        const uint64_t* d_scalars, size_t n, uint64_t* d_windows, int* n_windows,
                        int* window_bits) {
@@ -881,6 +903,49 @@ int bp_range_agg_eval(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uin
   HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, dout, 32, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(t_hat, ctx->pinned, 32);
+  return BP_OK;
+}
+
+int bp_range_agg_verify_scalars(bp_ctx* ctx, int curve, const uint64_t* challenges, const uint64_t* challenge_invs,
+                                size_t k, const uint64_t a[4], const uint64_t b[4], const uint64_t y_inv[4],
+                                const uint64_t z[4], size_t m, unsigned n_bits, uint64_t* out_g, uint64_t* out_h) {
+  if (!ctx || !a || !b || !y_inv || !z || !out_g || !out_h || (k && (!challenges || !challenge_invs)))
+    return fail(ctx, BP_E_ARG, "bp_range_agg_verify_scalars: null argument");
+  if (k > 28 || m == 0 || n_bits == 0 || n_bits > 64 || m * (size_t)n_bits != ((size_t)1 << k))
+    return fail(ctx, BP_E_ARG, "bp_range_agg_verify_scalars: m * n_bits must be 2^k");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  const size_t n = (size_t)1 << k;
+  std::vector<uint64_t> tab(4 * (m + n_bits));
+  if (curve == BP_SECP256K1)
+    range_tables<Secp256k1Fr>(z, m, n_bits, tab.data(), tab.data() + 4 * m);
+  else
+    range_tables<VestaFr>(z, m, n_bits, tab.data(), tab.data() + 4 * m);
+  void *dch = nullptr, *dchi = nullptr, *dtab, *dt, *dss, *dssi, *dyi, *dg, *dh;
+  if (k) {
+    CHK(upload(ctx, S_IN0, challenges, k * 32, &dch));
+    CHK(upload(ctx, S_IN1, challenge_invs, k * 32, &dchi));
+  }
+  CHK(upload(ctx, S_IN2, tab.data(), tab.size() * 8, &dtab));
+  size_t te = s_vector_table_elems((int)k), pe = powers_table_elems(n);
+  CHK(reserve(ctx, S_TABLE, (te > pe ? te : pe) * 32, &dt));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dss));
+  CHK(reserve(ctx, S_OUT1, n * 32, &dssi));
+  CHK(reserve(ctx, S_OUT2, n * 32, &dyi));
+  CHK(reserve(ctx, S_IN5, n * 32, &dg));
+  CHK(reserve(ctx, S_IN6, n * 32, &dh));
+  // the launches share the table buffer; they run one after the other on the context's stream
+  hipError_t e = launch_s_vector(curve, (const u32*)dch, (const u32*)dchi, (int)k, (u32*)dt, (u32*)dss, ctx->stream);
+  if (e == hipSuccess) e = launch_s_vector(curve, (const u32*)dchi, (const u32*)dch, (int)k, (u32*)dt, (u32*)dssi, ctx->stream);
+  if (e == hipSuccess) e = launch_powers(curve, to_arg(y_inv), n, (u32*)dt, (u32*)dyi, ctx->stream);
+  if (e == hipSuccess)
+    e = launch_range_verify_scalars(curve, (const u32*)dss, (const u32*)dssi, (const u32*)dyi, (const u32*)dtab,
+                                    (const u32*)dtab + 8 * m, n_bits, n, to_arg(a), to_arg(b), to_arg(z), (u32*)dg,
+                                    (u32*)dh, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "range_verify_scalars", e);
+  HIPCHK(ctx, hipMemcpyAsync(out_g, dg, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out_h, dh, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return BP_OK;
 }
 

@@ -3,6 +3,7 @@
 // One 256-bit element = 32 contiguous bytes; a wave reads/writes 2 KiB runs.
 #include "bp_field.h"
 #include "bp_internal.h"
+#include "bp_range.h"
 
 namespace bp {
 
@@ -465,6 +466,34 @@ hipError_t launch_range_eval(int curve, const u32* l0, const u32* l1, const u32*
     hipLaunchKernelGGL(k_range_eval<F>, dim3(blocks), dim3(256), 0, st, l0, l1, r0, r1, n, x, l, r, partials);
     hipLaunchKernelGGL(k_dot_final<F>, dim3(1), dim3(256), 0, st, partials, (int)blocks, out);
   });
+  return hipGetLastError();
+}
+
+// The verifier's side: by linearity the checks of src/range/aggregate.rs:217-279 are one MSM whose
+// gs_i and hs_i scalars collect the inner-product argument's a*s_i, b*s_i^-1 (src/ipa/mod.rs:160,166),
+// the y^-i of hs' (:272) and the -z, z y^i + z^(2+j) 2^i of P (:239-261).
+template <class F>
+__global__ __launch_bounds__(256) void k_range_verify_scalars(const u32* __restrict__ ss, const u32* __restrict__ ssi,
+                                                              const u32* __restrict__ yinv, const u32* __restrict__ zpow,
+                                                              const u32* __restrict__ pow2, unsigned n_bits, size_t n,
+                                                              FeArg aa, FeArg ba, FeArg za, u32* __restrict__ g,
+                                                              u32* __restrict__ h) {
+  const Fe a = arg_to_fe(aa), b = arg_to_fe(ba), z = arg_to_fe(za);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t j = i / n_bits;
+  const unsigned bit = (unsigned)(i % n_bits);
+  fe_store(g + i * 8, fe_add<F>(fe_mul<F>(a, fe_load(ss + i * 8)), z));
+  const Fe t = fe_sub<F>(fe_mul<F>(b, fe_load(ssi + i * 8)), fe_mul<F>(fe_load(zpow + j * 8), fe_load(pow2 + bit * 8)));
+  fe_store(h + i * 8, fe_sub<F>(fe_mul<F>(fe_load(yinv + i * 8), t), z));
+}
+
+hipError_t launch_range_verify_scalars(int curve, const u32* ss, const u32* ssi, const u32* yinv, const u32* zpow,
+                                       const u32* pow2, unsigned n_bits, size_t n, FeArg a, FeArg b, FeArg z, u32* g,
+                                       u32* h, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_range_verify_scalars<F>, dim3(blocks), dim3(256), 0, st, ss, ssi, yinv, zpow,
+                                        pow2, n_bits, n, a, b, z, g, h));
   return hipGetLastError();
 }
 

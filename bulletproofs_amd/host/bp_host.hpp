@@ -73,6 +73,7 @@ struct ScalarOps {
   static Scalar neg(const Scalar& a) { return from(h_neg<Fr>(to(a))); }
   // Fermat inverse with Montgomery products: Montgomery form in, Montgomery form out
   static Scalar inv(const Scalar& a) { return from(h_inv<Fr>(to(a))); }
+  static bool is_zero(const Scalar& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
   static Scalar to_mont(const Scalar& canonical) {
     HFe r2{{Fr::r264(0), Fr::r264(1), Fr::r264(2), Fr::r264(3)}};
     return from(h_mul<Fr>(to(canonical), r2));
@@ -190,6 +191,18 @@ class Msm {
  public:
   using S = ScalarOps<Fr>;
   explicit Msm(bp_ctx* ctx) : ctx_(ctx) {}
+  // An accumulator whose bases are mostly points of a registered base set (a CRS): those are
+  // addressed by their index in the set and keep their scalars in a dense vector, so that
+  // neither a hash lookup per generator nor an upload of the generators is needed; any other
+  // point goes through the map as before.  The group element of execute() is that of the
+  // plain accumulator holding the same (base, scalar) pairs.
+  Msm(bp_ctx* ctx, const bp_bases* bases, size_t n_bases) : ctx_(ctx), bases_(bases), dense_(n_bases, S::zero()) {}
+  void upsert_resident(size_t index, const Scalar& scalar) { dense_.at(index) = S::add(dense_.at(index), scalar); }
+  void upsert_resident_range(size_t offset, const std::vector<Scalar>& scalars) {
+    if (offset + scalars.size() > dense_.size()) throw std::out_of_range("resident range");
+    for (size_t i = 0; i < scalars.size(); i++) dense_[offset + i] = S::add(dense_[offset + i], scalars[i]);
+  }
+  void scale_resident(size_t index, const Scalar& factor) { dense_.at(index) = S::mul(dense_.at(index), factor); }
   // src/msm.rs:33-38
   void upsert(const Affine& base, const Scalar& scalar) {
     auto it = map_.find(base);
@@ -201,7 +214,10 @@ class Msm {
     for (size_t i = 0; i < n; i++) upsert(bases[i], scalars[i]);
   }
   // src/msm.rs:50-54
-  void scale(const Scalar& s) { for (auto& kv : map_) kv.second = S::mul(kv.second, s); }
+  void scale(const Scalar& s) {
+    for (auto& kv : map_) kv.second = S::mul(kv.second, s);
+    for (auto& v : dense_) v = S::mul(v, s);
+  }
   // src/msm.rs:62-71
   void scale_elems(const std::vector<Affine>& bases, const std::vector<Scalar>& factors) {
     for (size_t i = 0; i < bases.size() && i < factors.size(); i++) {
@@ -210,7 +226,13 @@ class Msm {
     }
   }
   // src/msm.rs:73-77
-  void batch(const Msm& rhs) { for (auto& kv : rhs.map_) upsert(kv.first, kv.second); }
+  void batch(const Msm& rhs) {
+    for (auto& kv : rhs.map_) upsert(kv.first, kv.second);
+    if (!rhs.dense_.empty()) {
+      if (bases_ != rhs.bases_ || dense_.size() != rhs.dense_.size()) throw std::invalid_argument("accumulators over different base sets");
+      for (size_t i = 0; i < dense_.size(); i++) dense_[i] = S::add(dense_[i], rhs.dense_[i]);
+    }
+  }
   size_t size() const { return map_.size(); }
   // src/msm.rs:79-87: one MSM over the de-duplicated map (iteration order is unspecified
   // there too; the group element does not depend on it)
@@ -225,13 +247,20 @@ class Msm {
       i++;
     }
     Projective out;
-    check(ctx_, bp_msm(ctx_, CURVE, x.data(), y.data(), inf.data(), s.data(), n, out.xyz), "bp_msm");
+    if (bases_)
+      check(ctx_, bp_msm_resident_plus(ctx_, bases_, 0, dense_.size(), dense_.empty() ? nullptr : dense_[0].l, x.data(),
+                                       y.data(), inf.data(), s.data(), n, out.xyz), "bp_msm_resident_plus");
+    else
+      check(ctx_, bp_msm(ctx_, CURVE, x.data(), y.data(), inf.data(), s.data(), n, out.xyz), "bp_msm");
     return out;
   }
   bp_ctx* ctx() const { return ctx_; }
+  Msm empty_like() const { return bases_ ? Msm(ctx_, bases_, dense_.size()) : Msm(ctx_); }
 
  private:
   bp_ctx* ctx_;
+  const bp_bases* bases_ = nullptr;
+  std::vector<Scalar> dense_;  // scalar of bases_[i]
   std::unordered_map<Affine, Scalar, AffineHash> map_;
 };
 
@@ -243,7 +272,7 @@ bool verify_batch_aux(std::vector<M>& proofs, const Scalar& alpha) {
   using S = typename M::S;
   if (proofs.empty()) throw std::invalid_argument("non-empty vec");
   Scalar pw = S::one();
-  M acc(proofs[0].ctx());
+  M acc = proofs[0].empty_like();
   for (size_t k = 0; k < proofs.size(); k++) {
     proofs[k].scale(pw);
     acc.batch(proofs[k]);

@@ -216,6 +216,15 @@ int range_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const u
       bool good = is_zero(msm.execute());  // src/range/aggregate.rs:294-299
       auto d = std::chrono::steady_clock::now();
       if (!good) *ok = 0;
+      if (r == 0) {
+        // the verifier in the reference's order of operations reaches the same group element
+        // (the identity for a valid proof, some other point for a corrupted one)
+        SeededTranscript<Fr> t3(seed_chal);
+        SeededRandom<Fr> vrng3(seed_rand ^ 0x5EEDull);
+        Projective stepwise = R::verify_aux_stepwise(ctx, crs, vcom, n_bits, check_proof, t3, vrng3).execute();
+        if (memcmp(stepwise.xyz, msm.execute().xyz, 96) != 0)
+          throw std::runtime_error("single-MSM verifier and stepwise verifier disagree");
+      }
       tp += std::chrono::duration<double, std::milli>(b - a).count();
       tv += std::chrono::duration<double, std::milli>(d - c).count();
     }

@@ -159,9 +159,90 @@ struct RangeAggregate {
     return pr;
   }
 
+  // src/range/aggregate.rs:173-282 as ONE deferred MSM.  The reference evaluates three group
+  // expressions on the way (the V_j combination :226, P :259-264, the T1/T2 terms :222-224) and
+  // hands the inner-product verifier a point; every one of them enters the returned accumulator
+  // linearly, so the same group element is reached by adding their terms to the accumulator
+  // instead: gs_i and hs_i collect a*s_i + z and y^-i (b*s_i^-1 - z^(2+j) 2^i) - z (built on the
+  // device, bp_range_agg_verify_scalars), and A, S, T1, T2, V_j, L_j, R_j, g, h, u carry the rest.
+  // execute() returns the point verify_aux_stepwise's accumulator evaluates to.
+  static M verify_aux(bp_ctx* ctx, const Crs& crs, const std::vector<Projective>& v_commit, unsigned n_bits,
+                      const RangeProof& pr, Transcript& t, RandomSource& rng) {
+    const size_t m = v_commit.size(), n = (size_t)n_bits * m;
+    if (n != crs.n) throw std::invalid_argument("CRS registered for another size");
+    const Scalar one = S::one();
+    Projective as[2] = {pr.a, pr.s};
+    t.prover_points(as, 2);
+    Scalar y = t.verifier_scalar(), z = t.verifier_scalar();
+    Projective tt[2] = {pr.tt1, pr.tt2};
+    t.prover_points(tt, 2);
+    Scalar x = t.verifier_scalar();
+    Scalar msg[3] = {pr.tao_x, pr.mu, pr.t_hat};
+    t.prover_scalars(msg, 3);
+    Scalar xe = t.verifier_scalar();
+    // the inner-product argument's challenges (src/ipa/mod.rs:116-132)
+    const size_t k = pr.ipa.L.size();
+    if (((size_t)1 << k) != n) throw std::invalid_argument("proof of another size");
+    std::vector<Scalar> xs(k), xinv(k);
+    for (size_t j = 0; j < k; j++) {
+      Projective lr[2] = {pr.ipa.L[j], pr.ipa.R[j]};
+      t.prover_points(lr, 2);
+      xs[j] = t.verifier_scalar();
+      xinv[j] = S::inv(xs[j]);
+    }
+    Scalar zz = S::mul(z, z), y_inv = S::inv(y);
+    // delta(y,z) = (z - z^2) <1, y^N> - sum_j z^(3+j) <1, 2^n>   (:209-215); <1, y^N> = (y^N - 1)/(y - 1)
+    Scalar sum_y;
+    {
+      Scalar yn = one, base = y;
+      for (size_t e = n; e; e >>= 1) { if (e & 1) yn = S::mul(yn, base); base = S::mul(base, base); }
+      Scalar ym1 = sub(y, one);
+      sum_y = S::is_zero(ym1) ? from_u64(n) : S::mul(sub(yn, one), S::inv(ym1));
+    }
+    Scalar two = from_u64(2), d = S::zero(), p2 = one;
+    for (unsigned i = 0; i < n_bits; i++) { d = S::add(d, p2); p2 = S::mul(p2, two); }
+    Scalar zsum = S::zero(), zp = S::mul(zz, z);
+    for (size_t j = 0; j < m; j++) { zsum = S::add(zsum, zp); zp = S::mul(zp, z); }
+    Scalar delta = sub(S::mul(sub(z, zz), sum_y), S::mul(zsum, d));
+    // scalars of gs and hs
+    std::vector<Scalar> gsc(n), hsc(n);
+    Scalar dummy = one;
+    check(ctx, bp_range_agg_verify_scalars(ctx, CURVE, k ? xs[0].l : dummy.l, k ? xinv[0].l : dummy.l, k, pr.ipa.a.l,
+                                           pr.ipa.b.l, y_inv.l, z.l, m, n_bits, gsc[0].l, hsc[0].l),
+          "bp_range_agg_verify_scalars");
+    M msm(ctx, crs.gh, 2 * n + 1);
+    msm.upsert_resident_range(0, gsc);
+    msm.upsert_resident_range(n, hsc);
+    // u: a*b*x' from the inner-product verifier (src/ipa/mod.rs:125, scale_elem :270) minus x'*t_hat from P
+    msm.upsert_resident(2 * n, S::mul(xe, sub(S::mul(pr.ipa.a, pr.ipa.b), pr.t_hat)));
+    Scalar minus_one = S::neg(one);
+    // -P = -A - x S + mu h (+ the gs, hs and u parts above)   (:259-264)
+    msm.upsert(P::to_affine(pr.a), minus_one);
+    msm.upsert(P::to_affine(pr.s), S::neg(x));
+    msm.upsert(crs.h, pr.mu);
+    for (size_t j = 0; j < k; j++) {                                             // src/ipa/mod.rs:170-190
+      msm.upsert(P::to_affine(pr.ipa.L[j]), S::neg(S::mul(xs[j], xs[j])));
+      msm.upsert(P::to_affine(pr.ipa.R[j]), S::neg(S::mul(xinv[j], xinv[j])));
+    }
+    // rho * ((t_hat - delta) g + tao_x h - sum_j z^(2+j) V_j - x T1 - x^2 T2)   (:217-227, :278-279)
+    Scalar rho = rng.scalar();
+    msm.upsert(crs.g, S::mul(rho, sub(pr.t_hat, delta)));
+    msm.upsert(crs.h, S::mul(rho, pr.tao_x));
+    zp = zz;
+    for (size_t j = 0; j < m; j++) {
+      msm.upsert(P::to_affine(v_commit[j]), S::neg(S::mul(rho, zp)));
+      zp = S::mul(zp, z);
+    }
+    msm.upsert(P::to_affine(pr.tt1), S::neg(S::mul(rho, x)));
+    msm.upsert(P::to_affine(pr.tt2), S::neg(S::mul(rho, S::mul(x, x))));
+    return msm;
+  }
+
+  // The same verifier in the reference's order of operations (every intermediate group element
+  // computed as there); kept as the cross-check of verify_aux.
   // src/range/aggregate.rs:173-282: returns the deferred MSM that must evaluate to zero.
   // v_commit: the m value commitments V_j = v_j g + gamma_j h.
-  static M verify_aux(bp_ctx* ctx, const Crs& crs, const std::vector<Projective>& v_commit, unsigned n_bits,
+  static M verify_aux_stepwise(bp_ctx* ctx, const Crs& crs, const std::vector<Projective>& v_commit, unsigned n_bits,
                       const RangeProof& pr, Transcript& t, RandomSource& rng) {
     const size_t m = v_commit.size(), n = (size_t)n_bits * m;
     const Scalar one = S::one();

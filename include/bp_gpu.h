@@ -115,6 +115,13 @@ int bp_bases_precompute(bp_bases* b);
  * src/ipa/types.rs:81-82). */
 int bp_msm_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
                     const uint64_t* scalars, uint64_t out_xyz[12]);
+/* sum_{i<n} scalars[i] * bases[offset + i] + sum_{j<n_extra} extra_scalars[j] * extra_j: the
+ * deferred MSM of a verifier (Msm::execute, src/msm.rs:84-87) whose bases are mostly CRS points:
+ * those stay on the device, only the scalars and the few other points (proof elements,
+ * commitments) are uploaded.  extra_inf may be NULL. */
+int bp_msm_resident_plus(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n, const uint64_t* scalars,
+                         const uint64_t* extra_x, const uint64_t* extra_y, const uint8_t* extra_inf,
+                         const uint64_t* extra_scalars, size_t n_extra, uint64_t out_xyz[12]);
 /* Two sums over the same n registered points in one pass: out_a = sum scalars_a[i] * P_i,
  * out_b = sum scalars_b[i] * P_i.  The A and S commitments of the range proofs, which the
  * reference computes side by side under rayon::join (src/range/aggregate.rs:80-83,
@@ -181,6 +188,14 @@ int bp_range_agg_poly(bp_ctx* ctx, int curve, const uint64_t* values, size_t m, 
  * bp_range_agg_poly of this context left; n must be that call's m * n_bits (BP_E_STATE otherwise). */
 int bp_range_agg_eval(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* l, uint64_t* r,
                       uint64_t t_hat[4]);
+/* Scalars of gs_i and hs_i (i = j*n_bits + bit, n = m*n_bits = 2^k) in the single deferred MSM that
+ * the checks of range::aggregate::verify_aux add up to by linearity:
+ *   out_g[i] = a*s_i + z                                    (src/ipa/mod.rs:134-160; src/range/aggregate.rs:239-245)
+ *   out_h[i] = y^-i * (b*s_i^-1 - z^(2+j) 2^bit) - z        (src/ipa/mod.rs:150-166; src/range/aggregate.rs:246-261,272)
+ * with s the s-vector of the k challenges, a, b the proof's final scalars.  Built on the device. */
+int bp_range_agg_verify_scalars(bp_ctx* ctx, int curve, const uint64_t* challenges, const uint64_t* challenge_invs,
+                                size_t k, const uint64_t a[4], const uint64_t b[4], const uint64_t y_inv[4],
+                                const uint64_t z[4], size_t m, unsigned n_bits, uint64_t* out_g, uint64_t* out_h);
 /* out[i] = x^i, i < n: powers_of_x src/poly_commit/mod.rs:16-22, y_vec
  * src/range/aggregate.rs:88-91, hs' scalars src/range/utils.rs:22-29. */
 int bp_powers(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* out);

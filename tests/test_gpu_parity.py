@@ -191,6 +191,28 @@ def test_range_agg_vector_polynomials(ctx, c, m, n_bits):
         ctx.range_agg_eval(c.id, f([x]), n + 1)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("m,n_bits", [(1, 1), (1, 8), (2, 4), (4, 16), (64, 64)])
+def test_range_agg_verifier_scalars(ctx, c, m, n_bits):
+    """gs_i: a*s_i + z; hs_i: y^-i (b*s_i^-1 - z^(2+j) 2^i) - z (src/ipa/mod.rs:134-166,
+    src/range/aggregate.rs:239-261,272) against the big-integer restatement"""
+    n = m * n_bits
+    k = n.bit_length() - 1
+    rng = o.SplitMix64(0xE1F + n)
+    ch = rng.scalars(k, c.n)
+    chi = [pow(v, -1, c.n) for v in ch]
+    a, b, y, z = (rng.field(c.n) for _ in range(4))
+    yi = pow(y, -1, c.n)
+    f = lambda v: o.pack_field(v, c.n)  # noqa: E731
+    g, h = ctx.range_agg_verify_scalars(c.id, f(ch).reshape(k, 4), f(chi).reshape(k, 4), f([a]), f([b]), f([yi]), f([z]),
+                                        m, n_bits)
+    ss = o.s_vector(ch, c.n) if k else [1]
+    eg = [(a * ss[i] + z) % c.n for i in range(n)]
+    eh = [(pow(yi, i, c.n) * (b * pow(ss[i], -1, c.n) - pow(z, 2 + i // n_bits, c.n) * (1 << (i % n_bits))) - z) % c.n
+          for i in range(n)]
+    assert o.unpack_field(g, c.n) == eg and o.unpack_field(h, c.n) == eh
+
+
 # ---- MSM ----------------------------------------------------------------------------
 
 
@@ -427,6 +449,14 @@ def test_msm_resident_and_two_part(ctx, coracle, c):
         ga, gb = bases.msm_pair(A[:cnt], B[:cnt], off, cnt)
         assert np.array_equal(ga, coracle.msm(c.id, pts, A[:cnt], 4)), (off, cnt)
         assert np.array_equal(gb, coracle.msm(c.id, pts, B[:cnt], 4)), (off, cnt)
+    # registered points plus uploaded ones = the concatenated MSM (Msm::execute, src/msm.rs:84-87)
+    ex, ey = seeded_points(coracle, c, 37, 91, 7)
+    einf = np.zeros(37, dtype=np.uint8)
+    einf[3] = 1
+    for off, cnt, k in ((0, n, 37), (10, 500, 1), (0, 0, 37), (5, 100, 0)):
+        exp = coracle.msm(c.id, (np.concatenate([px[off:off + cnt], ex[:k]]), np.concatenate([py[off:off + cnt], ey[:k]]),
+                                 np.concatenate([inf[off:off + cnt], einf[:k]])), np.concatenate([K[:cnt], K2[:k]]), 4)
+        assert np.array_equal(bases.msm_plus(K[:cnt], (ex[:k], ey[:k], einf[:k]), K2[:k], off, cnt), exp), (off, cnt, k)
     bases.free()
     big = 12000  # 2 x 12000 points: beyond the one-launch front end
     bx, by = seeded_points(coracle, c, big, 5, 3)
