@@ -384,6 +384,44 @@ struct Ipa {
     return proof;
   }
 
+  // ipa::verify_aux over a CRS that is registered on the GPU as gs = bases[g_off..g_off+n),
+  // hs = bases[h_off..h_off+n), u = bases[u_index] (n_bases points in all): the same accumulator
+  // content as verify_aux below, with the CRS scalars addressed by index, so the verifier neither
+  // hashes nor uploads 2n generators.
+  static Msm<Fq, Fr, CURVE> verify_aux_resident(bp_ctx* ctx, const bp_bases* bases, size_t n_bases, size_t g_off,
+                                                size_t h_off, size_t u_index, const Projective& p, size_t n,
+                                                const IpaProof& proof, Transcript& t) {
+    size_t k = proof.L.size();
+    std::vector<Scalar> xs(k), xinv(k);
+    for (size_t j = 0; j < k; j++) {
+      Projective lr[2] = {proof.L[j], proof.R[j]};
+      t.prover_points(lr, 2);
+      xs[j] = t.verifier_scalar();
+      xinv[j] = S::inv(xs[j]);                                                  // :128-132
+    }
+    Msm<Fq, Fr, CURVE> msm(ctx, bases, n_bases);
+    msm.upsert_resident(u_index, S::mul(proof.a, proof.b));                     // :125
+    std::vector<Scalar> ss(n), ssi(n);
+    if (k) {
+      check(ctx, bp_s_vector(ctx, CURVE, xs[0].l, xinv[0].l, k, ss[0].l), "bp_s_vector");   // :134-148
+      check(ctx, bp_s_vector(ctx, CURVE, xinv[0].l, xs[0].l, k, ssi[0].l), "bp_s_vector");  // :150-154
+    } else {
+      ss[0] = S::one(); ssi[0] = S::one();
+    }
+    std::vector<Scalar> as(n), bs(n);
+    check(ctx, bp_vec_op(ctx, CURVE, BP_VEC_SCALE, ss[0].l, nullptr, proof.a.l, n, as[0].l), "bp_vec_op");   // :160
+    check(ctx, bp_vec_op(ctx, CURVE, BP_VEC_SCALE, ssi[0].l, nullptr, proof.b.l, n, bs[0].l), "bp_vec_op");  // :166
+    msm.upsert_resident_range(g_off, as);
+    msm.upsert_resident_range(h_off, bs);
+    Scalar minus_one = S::neg(S::one());                                        // :170-190
+    msm.upsert(P::to_affine(p), minus_one);
+    for (size_t j = 0; j < k; j++) {
+      msm.upsert(P::to_affine(proof.L[j]), S::mul(minus_one, S::mul(xs[j], xs[j])));
+      msm.upsert(P::to_affine(proof.R[j]), S::mul(minus_one, S::mul(xinv[j], xinv[j])));
+    }
+    return msm;
+  }
+
   // ipa::verify_aux, src/ipa/mod.rs:102-193; challenges are re-derived from the transcript
   static Msm<Fq, Fr, CURVE> verify_aux(bp_ctx* ctx, const Crs& crs, const Projective& p, size_t n, const IpaProof& proof,
                                        Transcript& t) {

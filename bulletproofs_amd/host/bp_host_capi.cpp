@@ -77,13 +77,26 @@ int ipa_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uin
   crs.u.inf = 0;
   size_t k = 0;
   while (((size_t)1 << k) < n) k++;
+  // the CRS once on the GPU as gs || hs || u: proofs after the first and every verifier use it
+  bp_bases* gh = nullptr;
+  {
+    std::vector<uint64_t> x(8 * n + 4), y(8 * n + 4);
+    std::vector<uint8_t> inf(2 * n + 1, 0);
+    memcpy(&x[0], gx, 32 * n); memcpy(&y[0], gy, 32 * n);
+    memcpy(&x[4 * n], hx, 32 * n); memcpy(&y[4 * n], hy, 32 * n);
+    memcpy(&x[8 * n], u_xy, 32); memcpy(&y[8 * n], u_xy + 4, 32);
+    check(ctx, bp_bases_register(ctx, CURVE, x.data(), y.data(), inf.data(), 2 * n + 1, &gh), "bp_bases_register");
+  }
+  struct Release { bp_bases* b; ~Release() { bp_bases_free(b); } } release{gh};
   std::vector<Msm<Fq, Fr, CURVE>> msms;
   *single_ok = 1;
   for (size_t pi = 0; pi < n_proofs; pi++) {
     auto wa = unpack_s(a + 4 * n * pi, n), wb = unpack_s(b + 4 * n * pi, n);
     Projective p = I::statement(ctx, crs, wa, wb);
     SeededTranscript<Fr> tp(seed + 1000 * pi);
-    IpaProof proof = I::prove(ctx, crs, wa, wb, tp);
+    // first proof: generators handed over with the call, as ipa::prove does; the others: resident CRS
+    IpaProof proof = pi == 0 ? I::prove(ctx, crs, wa, wb, tp)
+                             : I::prove_resident(ctx, gh, 0, n, nullptr, 2 * n, ScalarOps<Fr>::one(), wa, wb, tp);
     if (pi == 0) {
       for (size_t j = 0; j < k; j++) {
         memcpy(out_l + 12 * j, proof.L[j].xyz, 96);
@@ -95,9 +108,16 @@ int ipa_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uin
     }
     if (tamper && pi == n_proofs - 1) proof.a = ScalarOps<Fr>::add(proof.a, ScalarOps<Fr>::one());
     SeededTranscript<Fr> tv(seed + 1000 * pi);
-    auto m = I::verify_aux(ctx, crs, p, n, proof, tv);
+    auto m = I::verify_aux_resident(ctx, gh, 2 * n + 1, 0, n, 2 * n, p, n, proof, tv);
     // ipa::verify, src/ipa/mod.rs:196-212
-    if (!is_zero(m.execute())) *single_ok = 0;
+    Projective value = m.execute();
+    if (!is_zero(value)) *single_ok = 0;
+    if (pi == 0 || pi == n_proofs - 1) {
+      // the accumulator keyed by points (verify_aux) evaluates to the same group element
+      SeededTranscript<Fr> tw(seed + 1000 * pi);
+      if (memcmp(I::verify_aux(ctx, crs, p, n, proof, tw).execute().xyz, value.xyz, 96) != 0)
+        throw std::runtime_error("indexed and keyed accumulators disagree");
+    }
     msms.push_back(std::move(m));
   }
   SeededTranscript<Fr> ta(seed ^ 0xA1FAull);
