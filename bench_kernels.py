@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel measurements behind DESIGN.md's table: streaming kernels in GB/s of
+"""Per-kernel measurements: streaming kernels in GB/s of
 algorithmic bytes, curve kernels in outputs/s and MAC/s, MSM over sizes, one IPA
 prove of n = 2^16.  Prints one JSON object per line.  Inputs are resident in HBM;
 timings are HIP-event durations reported by the library (bp_last_kernel_ms) or
