@@ -121,6 +121,98 @@ inline HFe h_inv(const HFe& a) {  // a^(p-2); 0 -> 0
   }
   return r;
 }
+// a^-1 by Kaliski's almost-inverse: phase 1 finds a^-1 2^k (256 <= k <= 512) with plain shifts,
+// additions and subtractions (nothing is reduced on the way: r and s stay below 2p), phase 2
+// multiplies the power of two away.  In and out in Montgomery form; 0 -> 0.  Variable time: for
+// public values (challenges, normalisation of results).
+template <class F>
+inline HFe h_inv_kaliski(const HFe& a) {
+  if (h_is_zero(a)) return a;
+  typedef unsigned long long ull;
+  ull u[4] = {F::mod64(0), F::mod64(1), F::mod64(2), F::mod64(3)}, v[4] = {a.v[0], a.v[1], a.v[2], a.v[3]};
+  ull r[5] = {0, 0, 0, 0, 0}, s[5] = {1, 0, 0, 0, 0};
+  auto shr1 = [](ull* x) {
+    x[0] = (x[0] >> 1) | (x[1] << 63);
+    x[1] = (x[1] >> 1) | (x[2] << 63);
+    x[2] = (x[2] >> 1) | (x[3] << 63);
+    x[3] >>= 1;
+  };
+  auto shl1 = [](ull* x) {
+    x[4] = (x[4] << 1) | (x[3] >> 63);
+    x[3] = (x[3] << 1) | (x[2] >> 63);
+    x[2] = (x[2] << 1) | (x[1] >> 63);
+    x[1] = (x[1] << 1) | (x[0] >> 63);
+    x[0] <<= 1;
+  };
+  auto gt = [](const ull* x, const ull* y) {
+    for (int i = 3; i >= 0; i--)
+      if (x[i] != y[i]) return x[i] > y[i];
+    return false;
+  };
+  auto subn = [](ull* x, const ull* y, int n) {  // x -= y over n limbs
+    ull b = 0;
+    for (int i = 0; i < n; i++) {
+      u128 d = (u128)x[i] - y[i] - b;
+      x[i] = (ull)d;
+      b = (ull)(d >> 64) & 1;
+    }
+  };
+  auto sub4 = [&subn](ull* x, const ull* y) { subn(x, y, 4); };
+  auto add5 = [](ull* x, const ull* y) {
+    u128 c = 0;
+    for (int i = 0; i < 5; i++) {
+      c += (u128)x[i] + y[i];
+      x[i] = (ull)c;
+      c >>= 64;
+    }
+  };
+  int k = 0;
+  while (v[0] | v[1] | v[2] | v[3]) {
+    if (!(u[0] & 1)) {
+      shr1(u);
+      shl1(s);
+    } else if (!(v[0] & 1)) {
+      shr1(v);
+      shl1(r);
+    } else if (gt(u, v)) {
+      sub4(u, v);
+      shr1(u);
+      add5(r, s);
+      shl1(s);
+    } else {
+      sub4(v, u);
+      shr1(v);
+      add5(s, r);
+      shl1(r);
+    }
+    k++;
+  }
+  // r < 2p: a^-1 2^k = p - (r mod p)
+  const ull p[5] = {F::mod64(0), F::mod64(1), F::mod64(2), F::mod64(3), 0};
+  auto geq5 = [](const ull* x, const ull* y) {
+    for (int i = 4; i >= 0; i--)
+      if (x[i] != y[i]) return x[i] > y[i];
+    return true;
+  };
+  if (geq5(r, p)) subn(r, p, 5);
+  ull pr[4] = {p[0], p[1], p[2], p[3]};
+  sub4(pr, r);
+  HFe x{{pr[0], pr[1], pr[2], pr[3]}};
+  // x = (aR)^-1 2^k; wanted a^-1 R = x 2^(512 - k): Montgomery-multiply by 2^m R with m = 512 - k
+  // (h_mul(x, y) = x y / R), in steps of at most 250 bits so that 2^step is below every modulus
+  const HFe r2{{F::r264(0), F::r264(1), F::r264(2), F::r264(3)}};
+  int m = 512 - k;
+  while (true) {
+    int step = m > 250 ? 250 : m;
+    HFe pw{{0, 0, 0, 0}};
+    pw.v[step >> 6] = 1ull << (step & 63);
+    x = h_mul<F>(x, h_mul<F>(pw, r2));
+    m -= step;
+    if (m == 0) break;
+  }
+  return x;
+}
+
 template <class F>
 inline HFe h_from_mont(const HFe& a) {
   HFe one{{1, 0, 0, 0}};
@@ -194,7 +286,7 @@ inline void hx_to_xyz(const HXyzz& p, uint64_t out[12]) {
     memset(out + 8, 0, 32);
     return;
   }
-  HFe i3 = h_inv<F>(p.zzz);
+  HFe i3 = h_inv_kaliski<F>(p.zzz);
   HFe t = h_mul<F>(p.zz, i3);
   HFe i2 = h_sqr<F>(t);
   HFe x = h_mul<F>(p.x, i2), y = h_mul<F>(p.y, i3);

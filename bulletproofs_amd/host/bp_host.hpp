@@ -72,8 +72,26 @@ struct ScalarOps {
   static Scalar mul(const Scalar& a, const Scalar& b) { return from(h_mul<Fr>(to(a), to(b))); }
   static Scalar neg(const Scalar& a) { return from(h_neg<Fr>(to(a))); }
   // Fermat inverse with Montgomery products: Montgomery form in, Montgomery form out
-  static Scalar inv(const Scalar& a) { return from(h_inv<Fr>(to(a))); }
+  static Scalar inv(const Scalar& a) { return from(h_inv_kaliski<Fr>(to(a))); }  // public values only: variable time
   static bool is_zero(const Scalar& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+  // ark_ff::batch_inversion (src/ipa/mod.rs:128-132): one inversion and 3 multiplications per
+  // element; zeros stay zero
+  static void batch_inv(const std::vector<Scalar>& in, std::vector<Scalar>& out) {
+    const size_t n = in.size();
+    out.assign(n, zero());
+    std::vector<Scalar> pre(n);
+    Scalar run = one();
+    for (size_t i = 0; i < n; i++) {
+      pre[i] = run;
+      if (!is_zero(in[i])) run = mul(run, in[i]);
+    }
+    Scalar acc = inv(run);
+    for (size_t i = n; i-- > 0;) {
+      if (is_zero(in[i])) continue;
+      out[i] = mul(acc, pre[i]);
+      acc = mul(acc, in[i]);
+    }
+  }
   static Scalar to_mont(const Scalar& canonical) {
     HFe r2{{Fr::r264(0), Fr::r264(1), Fr::r264(2), Fr::r264(3)}};
     return from(h_mul<Fr>(to(canonical), r2));
@@ -397,8 +415,8 @@ struct Ipa {
       Projective lr[2] = {proof.L[j], proof.R[j]};
       t.prover_points(lr, 2);
       xs[j] = t.verifier_scalar();
-      xinv[j] = S::inv(xs[j]);                                                  // :128-132
     }
+    S::batch_inv(xs, xinv);                                                     // :128-132
     Msm<Fq, Fr, CURVE> msm(ctx, bases, n_bases);
     msm.upsert_resident(u_index, S::mul(proof.a, proof.b));                     // :125
     std::vector<Scalar> ss(n), ssi(n);
@@ -431,8 +449,8 @@ struct Ipa {
       Projective lr[2] = {proof.L[j], proof.R[j]};
       t.prover_points(lr, 2);
       xs[j] = t.verifier_scalar();
-      xinv[j] = S::inv(xs[j]);                                                  // batch_inversion :128-132
     }
+    S::batch_inv(xs, xinv);                                                     // batch_inversion :128-132
     Msm<Fq, Fr, CURVE> msm(ctx);
     msm.upsert(crs.u, S::mul(proof.a, proof.b));                                // :125
     std::vector<Scalar> ss(n), ssi(n);

@@ -188,16 +188,25 @@ struct RangeAggregate {
       Projective lr[2] = {pr.ipa.L[j], pr.ipa.R[j]};
       t.prover_points(lr, 2);
       xs[j] = t.verifier_scalar();
-      xinv[j] = S::inv(xs[j]);
     }
-    Scalar zz = S::mul(z, z), y_inv = S::inv(y);
+    // one inversion for the k challenges, y and y - 1 (ark_ff::batch_inversion, src/ipa/mod.rs:128-132)
+    Scalar y_inv, ym1_inv;
+    {
+      std::vector<Scalar> in(xs), out;
+      in.push_back(y);
+      in.push_back(sub(y, one));
+      S::batch_inv(in, out);
+      for (size_t j = 0; j < k; j++) xinv[j] = out[j];
+      y_inv = out[k];
+      ym1_inv = out[k + 1];
+    }
+    Scalar zz = S::mul(z, z);
     // delta(y,z) = (z - z^2) <1, y^N> - sum_j z^(3+j) <1, 2^n>   (:209-215); <1, y^N> = (y^N - 1)/(y - 1)
     Scalar sum_y;
     {
       Scalar yn = one, base = y;
       for (size_t e = n; e; e >>= 1) { if (e & 1) yn = S::mul(yn, base); base = S::mul(base, base); }
-      Scalar ym1 = sub(y, one);
-      sum_y = S::is_zero(ym1) ? from_u64(n) : S::mul(sub(yn, one), S::inv(ym1));
+      sum_y = S::is_zero(ym1_inv) ? from_u64(n) : S::mul(sub(yn, one), ym1_inv);
     }
     Scalar two = from_u64(2), d = S::zero(), p2 = one;
     for (unsigned i = 0; i < n_bits; i++) { d = S::add(d, p2); p2 = S::mul(p2, two); }
