@@ -108,6 +108,7 @@ SIGNATURES = {
     "bp_bench_int_mad_peak": (ci, [vp, ci, C.POINTER(C.c_double)]),
     "bp_microbench": (ci, [vp, ci, ci, ci, C.POINTER(C.c_float)]),
     "bp_last_kernel_ms": (ci, [vp, ci, C.POINTER(C.c_float)]),
+    "bp_set_timing": (ci, [vp, ci]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -100,6 +100,7 @@ struct bp_ctx {
   MsmPipe pipe;         // second and third stream of large MSMs
   int last_stages = 1;  // batches of the last MSM (its accumulation time is the sum over pipe.cs0/cs1)
   HostWorker worker;
+  bool timing = true;  // bp_set_timing
   // vector polynomials left on the device by bp_range_agg_poly for bp_range_agg_eval (S_RANGE)
   size_t range_n = 0;
   int range_curve = -1;
@@ -301,16 +302,20 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
   CHK(reserve(ctx, S_SEGS, plan->seg_bytes, &p)); ws.segs = (u32*)p;
   CHK(reserve(ctx, S_SEG_GROUPS, plan->seg_group_bytes, &p)); ws.seg_groups = (u32*)p;
   CHK(reserve(ctx, S_WINDOWS, plan->win_bytes, &p)); ws.windows = (u32*)p;
-  HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  // four event markers per MSM cost a few microseconds each on the stream: only with timing on
+  const bool timed = ctx->timing || plan->stages > 1;
+  if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->last_stages = plan->stages;
-  e = msm_run(curve, p0, p1, extra, *plan, ws, ctx->stream, ctx->ev[2], ctx->ev[3], table, &ctx->pipe);
+  e = msm_run(curve, p0, p1, extra, *plan, ws, ctx->stream, timed ? ctx->ev[2] : nullptr, timed ? ctx->ev[3] : nullptr,
+              table, &ctx->pipe);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "msm_run", e);
-  HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   *d_windows = ws.windows;
   return BP_OK;
 }
 
 void msm_collect_times(bp_ctx* ctx, bool had_points) {
+  if (!ctx->timing && ctx->last_stages <= 1) return;
   float ms = 0;
   if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_ms[1] = ms;
   if (!had_points) return;
@@ -1522,6 +1527,13 @@ int bp_microbench(bp_ctx* ctx, int id, int blocks, int iters, float* ms) {
   HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev[4], ctx->ev[5]));
+  return BP_OK;
+}
+
+int bp_set_timing(bp_ctx* ctx, int on) {
+  if (!ctx) return BP_E_ARG;
+  Guard g(ctx);
+  ctx->timing = on != 0;
   return BP_OK;
 }
 

@@ -294,6 +294,10 @@ int bp_bench_int_mad_peak(bp_ctx* ctx, int iters, double* mac_per_s);
  * (the MSM point-gather pattern with a known byte count, 64 * 2^iters, for calibrating
  * memory counters); `blocks` is ignored, 10 <= iters <= 26. */
 int bp_microbench(bp_ctx* ctx, int id, int blocks, int iters, float* ms);
+/* The event markers behind bp_last_kernel_ms for MSMs (four per MSM, a few microseconds each on the
+ * stream) can be turned off for latency-bound callers (the IPA rounds of a proof); on by default.
+ * No counterpart in the reference. */
+int bp_set_timing(bp_ctx* ctx, int on);
 /* Duration in ms of the most recent launch of the named kernel group on this
  * context, measured with HIP events on the context's stream.
  * groups: 0 = MSM bucket accumulation, 1 = whole MSM device phase, 2 = last
