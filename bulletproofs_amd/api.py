@@ -267,6 +267,10 @@ class Context:
         self._chk(lib.bp_bench_int_mad_peak(self.h, iters, C.byref(v)))
         return v.value
 
+    def set_timing(self, on):
+        """event markers around MSMs (bp_last_kernel_ms) on or off"""
+        self._chk(lib.bp_set_timing(self.h, 1 if on else 0))
+
     def last_kernel_ms(self, group):
         v = C.c_float()
         self._chk(lib.bp_last_kernel_ms(self.h, group, C.byref(v)))

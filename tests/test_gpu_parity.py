@@ -231,6 +231,26 @@ def test_msm_golden(ctx):
         assert got == pt_from_json(fx["expect"]), (fx["curve"], fx["case"], fx["n"])
 
 
+def test_msm_without_event_markers(ctx, coracle):
+    """bp_set_timing(0): same results on the small, mid-size and chunked paths, and the last
+    recorded durations stay as they were"""
+    c = o.SECP256K1
+    try:
+        for n in (300, 40000, 300000):
+            px, py = seeded_points(coracle, c, n, 3, 5)
+            _, K = random_scalars(c, n, n)
+            ctx.set_timing(True)
+            exp = ctx.msm_unchecked(c.id, (px, py, None), K)
+            before = ctx.last_kernel_ms(1)
+            assert before > 0
+            ctx.set_timing(False)
+            assert np.array_equal(ctx.msm_unchecked(c.id, (px, py, None), K), exp), n
+            assert ctx.last_kernel_ms(1) == before
+        assert np.array_equal(exp, coracle.msm(c.id, (px, py, None), K, 8))
+    finally:
+        ctx.set_timing(True)
+
+
 @pytest.mark.parametrize("c", CURVES, ids=ids)
 def test_msm_edge_shapes(ctx, c):
     empty_f = np.zeros((0, 4), dtype=np.uint64)
