@@ -136,3 +136,22 @@ for j in range(16):
     t_fold += time.perf_counter() - t0
 print(json.dumps({"kernel": "ipa_prove_rounds", "n": n, "upload_ms": t_begin * 1e3, "lr_ms": t_lr * 1e3, "fold_ms": t_fold * 1e3,
                   "total_ms": (t_lr + t_fold) * 1e3, "proofs_per_s": 1.0 / (t_lr + t_fold)}), flush=True)
+
+# ---- IPA verify, n = 2^16 (src/ipa/mod.rs:102-212): the s-vector and its inverse, their multiples
+# by a and b, and the deferred MSM over gs || hs || u (registered once) plus P, L_j, R_j ----
+# (u and the proof's points are stand-ins taken from the same table: values do not change the work)
+bases = ctx.register_bases(C, (np.concatenate([gx, hx, px[:1]]), np.concatenate([gy, hy, py[:1]]), None))
+extra = (px[1:34], py[1:34], None)
+extra_s = rand_field(33)
+pa, pb = rand_field(1), rand_field(1)
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    ss = ctx.s_vector(C, ch, chi)
+    ssi = ctx.s_vector(C, chi, ch)
+    sc = np.concatenate([ctx.scale(C, ss, pa), ctx.scale(C, ssi, pb), ctx.hadamard(C, pa, pb)])
+    bases.msm_plus(sc, extra, extra_s)
+    ts.append(time.perf_counter() - t0)
+print(json.dumps({"kernel": "ipa_verify", "n": n, "msm_points": 2 * n + 34, "total_ms": min(ts) * 1e3,
+                  "verifies_per_s": 1 / min(ts)}), flush=True)
+bases.free()
