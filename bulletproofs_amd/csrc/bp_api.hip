@@ -499,13 +499,20 @@ int bp_bases_register(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t*
   b->inf = nullptr;
   size_t bytes = n ? n * 32 : 32;
   hipError_t e;
+  // every exit but the last releases what was allocated so far
+  struct Undo {
+    bp_bases* b;
+    ~Undo() {
+      if (!b) return;
+      if (b->x) (void)hipFree(b->x);
+      if (b->y) (void)hipFree(b->y);
+      if (b->inf) (void)hipFree(b->inf);
+      delete b;
+    }
+  } undo{b};
   if ((e = hipMalloc((void**)&b->x, bytes)) != hipSuccess || (e = hipMalloc((void**)&b->y, bytes)) != hipSuccess ||
-      (e = hipMalloc((void**)&b->inf, n ? n : 1)) != hipSuccess) {
-    if (b->x) (void)hipFree(b->x);
-    if (b->y) (void)hipFree(b->y);
-    delete b;
+      (e = hipMalloc((void**)&b->inf, n ? n : 1)) != hipSuccess)
     return fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "bp_bases_register: hipMalloc", e);
-  }
   if (n) {
     HIPCHK(ctx, hipMemcpyAsync(b->x, x, n * 32, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(b->y, y, n * 32, hipMemcpyHostToDevice, ctx->stream));
@@ -515,6 +522,7 @@ int bp_bases_register(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t*
       HIPCHK(ctx, hipMemsetAsync(b->inf, 0, n, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
+  undo.b = nullptr;
   *out = b;
   return BP_OK;
 }
@@ -1231,9 +1239,9 @@ int bp_ipa_begin_resident(bp_ctx* ctx, const bp_bases* bases, int variant, size_
 int bp_ipa_scale_h(bp_ipa* s, const uint64_t* scale) {
   if (!s || !scale) return BP_E_ARG;
   bp_ctx* ctx = s->ctx;
+  Guard g(ctx);  // session state is read under the context's lock
   if (s->variant != BP_IPA_BULLETPROOF) return fail(ctx, BP_E_ARG, "bp_ipa_scale_h: session has no H vector");
   if (s->n != s->n0) return fail(ctx, BP_E_STATE, "bp_ipa_scale_h: only before the first fold");
-  Guard g(ctx);
   // ch *= scale: from here on the session behaves as if H_i had been scale_i * H_i
   HIPCHK(ctx, hipMemcpyAsync(s->eh, scale, s->n0 * 32, hipMemcpyHostToDevice, ctx->stream));
   hipError_t e = launch_vec_op(s->curve, BP_VEC_HADAMARD, s->ch, s->eh, FeArg{}, s->n0, s->ch, ctx->stream);
@@ -1258,9 +1266,9 @@ int bp_ipa_set_u(bp_ipa* s, const uint64_t u_xy[8]) {
 int bp_ipa_set_u_resident(bp_ipa* s, size_t u_index, const uint64_t factor[4]) {
   if (!s || !factor) return BP_E_ARG;
   bp_ctx* ctx = s->ctx;
+  Guard g(ctx);
   if (!s->res) return fail(ctx, BP_E_STATE, "bp_ipa_set_u_resident: session was not begun over a registered base set");
   if (u_index >= s->res->n) return fail(ctx, BP_E_ARG, "bp_ipa_set_u_resident: index outside the base set");
-  Guard g(ctx);
   // x|y side by side for plans that read the point itself
   HIPCHK(ctx, hipMemcpyAsync(s->u_xy, s->res->x + u_index * 8, 32, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(s->u_xy + 8, s->res->y + u_index * 8, 32, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1280,8 +1288,8 @@ size_t bp_ipa_len(const bp_ipa* s) { return s ? s->n : 0; }
 int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t c_l[4], uint64_t c_r[4]) {
   if (!s || !l_xyz || !r_xyz || !c_l || !c_r) return BP_E_ARG;
   bp_ctx* ctx = s->ctx;
-  if (s->n < 2) return fail(ctx, BP_E_STATE, "bp_ipa_round_lr: vectors already folded to length 1");
   Guard g(ctx);
+  if (s->n < 2) return fail(ctx, BP_E_STATE, "bp_ipa_round_lr: vectors already folded to length 1");
   const size_t h = s->n / 2, n0 = s->n0;
   const bool has_h = s->variant == BP_IPA_BULLETPROOF;
   const u32 *a_lo = s->a, *a_hi = s->a + h * 8, *b_lo = s->b, *b_hi = s->b + h * 8;
@@ -1421,8 +1429,9 @@ int bp_ipa_read(bp_ipa* s, uint64_t* gx, uint64_t* gy, uint8_t* ginf, uint64_t* 
     finish_windows(s->curve, win + (size_t)plan.group_windows * 16, plan.group_windows, plan.c, h_xyz);
     auto put = [](const uint64_t xyz[12], uint64_t* ox, uint64_t* oy, uint8_t* oinf) {
       bool inf = !(xyz[8] | xyz[9] | xyz[10] | xyz[11]);
-      if (ox) memcpy(ox, xyz, 32);
-      if (oy) memcpy(oy, xyz + 4, 32);
+      // affine outputs encode the identity as x = y = 0 with the flag set
+      if (ox) { if (inf) memset(ox, 0, 32); else memcpy(ox, xyz, 32); }
+      if (oy) { if (inf) memset(oy, 0, 32); else memcpy(oy, xyz + 4, 32); }
       if (oinf) *oinf = inf ? 1 : 0;
     };
     put(g_xyz, gx, gy, ginf);

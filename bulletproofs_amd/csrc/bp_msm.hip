@@ -197,6 +197,13 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
     size_t need = (size_t)p.n_windows * (p.tab ? p.entries : n_total) * sizeof(u32);
     if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
   }
+  if (p.mid) {
+    // the sliced counting sort keeps one histogram per (group, digit window, slice) in the second
+    // key buffer: a size that does not shrink with n (16 KiB per group at one slice)
+    const size_t n_slices = (n_total + kMidSlice - 1) / kMidSlice;
+    size_t need = (size_t)groups * p.digit_windows * n_slices * p.n_buckets * sizeof(u32);
+    if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
+  }
   // the chunked path sorts with the two-level counting sort when the bucket number has a high
   // part and the counters of all (window, partition) pairs fit one block
   p.two_level = !p.small && !p.mid && !p.tab && p.stages == 1 && n_total > 0 &&

@@ -59,6 +59,21 @@ struct PhaseTrace {
   }
 };
 
+// What the reference's verifiers return as Err(VerificationError) (src/lib.rs:9-10): a proof whose
+// shape does not fit the statement.  Drivers treat it as a rejection.
+struct VerificationError : std::runtime_error {
+  explicit VerificationError(const char* what) : std::runtime_error(what) {}
+};
+
+// log2 of the statement size must equal the number of (L, R) pairs the proof carries: the reference
+// reads exactly log2(n) pairs from the transcript (src/ipa/mod.rs:110-119), so a proof with more or
+// fewer rounds fails to deserialise there.  Checked before any allocation or device call.
+inline size_t checked_rounds(size_t n_l, size_t n_r, size_t n) {
+  if (n_l != n_r) throw VerificationError("proof with unequal numbers of L and R");
+  if (n_l >= 64 || (size_t(1) << n_l) != n) throw VerificationError("proof of another size than the statement");
+  return n_l;
+}
+
 inline void check(bp_ctx* ctx, int rc, const char* what) {
   if (rc != BP_OK) throw std::runtime_error(std::string(what) + ": " + bp_last_error(ctx));
 }
@@ -409,7 +424,7 @@ struct Ipa {
   static Msm<Fq, Fr, CURVE> verify_aux_resident(bp_ctx* ctx, const bp_bases* bases, size_t n_bases, size_t g_off,
                                                 size_t h_off, size_t u_index, const Projective& p, size_t n,
                                                 const IpaProof& proof, Transcript& t) {
-    size_t k = proof.L.size();
+    const size_t k = checked_rounds(proof.L.size(), proof.R.size(), n);
     std::vector<Scalar> xs(k), xinv(k);
     for (size_t j = 0; j < k; j++) {
       Projective lr[2] = {proof.L[j], proof.R[j]};
@@ -443,7 +458,8 @@ struct Ipa {
   // ipa::verify_aux, src/ipa/mod.rs:102-193; challenges are re-derived from the transcript
   static Msm<Fq, Fr, CURVE> verify_aux(bp_ctx* ctx, const Crs& crs, const Projective& p, size_t n, const IpaProof& proof,
                                        Transcript& t) {
-    size_t k = proof.L.size();
+    const size_t k = checked_rounds(proof.L.size(), proof.R.size(), n);
+    if (crs.gs.size() < n || crs.hs.size() < n) throw VerificationError("CRS smaller than the statement");
     std::vector<Scalar> xs(k), xinv(k);
     for (size_t j = 0; j < k; j++) {
       Projective lr[2] = {proof.L[j], proof.R[j]};

@@ -106,8 +106,22 @@ int ipa_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uin
       memcpy(out_ab + 4, proof.b.l, 32);
       memcpy(out_p, p.xyz, 96);
     }
-    if (tamper && pi == n_proofs - 1) proof.a = ScalarOps<Fr>::add(proof.a, ScalarOps<Fr>::one());
+    if (tamper == 1 && pi == n_proofs - 1) proof.a = ScalarOps<Fr>::add(proof.a, ScalarOps<Fr>::one());
+    if (tamper == 2 && pi == n_proofs - 1 && !proof.L.empty()) { proof.L.pop_back(); proof.R.pop_back(); }   // a round dropped
+    if (tamper == 3 && pi == n_proofs - 1) { proof.L.push_back(p); proof.R.push_back(p); }                   // a round appended
+    if (tamper == 4 && pi == n_proofs - 1) proof.R.push_back(p);                                             // ragged
     SeededTranscript<Fr> tv(seed + 1000 * pi);
+    if (tamper >= 2 && pi == n_proofs - 1) {
+      // a proof of the wrong shape is refused before any device work, by both accumulators
+      int refused = 0;
+      try { I::verify_aux_resident(ctx, gh, 2 * n + 1, 0, n, 2 * n, p, n, proof, tv); } catch (const VerificationError&) { refused++; }
+      SeededTranscript<Fr> tw(seed + 1000 * pi);
+      try { I::verify_aux(ctx, crs, p, n, proof, tw); } catch (const VerificationError&) { refused++; }
+      if (refused != 2) throw std::runtime_error("malformed proof not refused");
+      *single_ok = 0;
+      *batch_ok = 0;
+      return 0;
+    }
     auto m = I::verify_aux_resident(ctx, gh, 2 * n + 1, 0, n, 2 * n, p, n, proof, tv);
     // ipa::verify, src/ipa/mod.rs:196-212
     Projective value = m.execute();
@@ -200,9 +214,12 @@ struct SeededRandom : RandomSource {
 template <class Fq, class Fr, int CURVE>
 int range_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx, const uint64_t* hy,
                     const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma, size_t m, unsigned n_bits,
-                    uint64_t seed_rand, uint64_t seed_chal, int tamper, int reps, uint64_t* out_points,
-                    uint64_t* out_scalars, uint64_t* out_lr, double* prove_ms, double* verify_ms, int* ok) {
+                    uint64_t seed_rand, uint64_t seed_chal, int tamper, int reps, int single, uint64_t* out_points,
+                    uint64_t* out_scalars, uint64_t* out_lr, uint64_t* out_value, double* prove_ms, double* verify_ms,
+                    int* ok) {
   using R = RangeAggregate<Fq, Fr, CURVE>;
+  using R1 = Range<Fq, Fr, CURVE>;
+  if (single && m != 1) return BP_E_ARG;
   using PO = PointOps<Fq, Fr>;
   size_t n = (size_t)n_bits * m;
   typename R::Crs crs;
@@ -217,7 +234,9 @@ int range_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const u
   std::vector<Projective> vcom(m);
   for (size_t j = 0; j < m; j++)
     vcom[j] = PO::lower(hx_add<Fq>(PO::mul(PO::lift(crs.g), R::from_u64(vals[j])), PO::mul(PO::lift(crs.h), gam[j])));
+  if (single && memcmp(R1::statement(crs, vals[0], gam[0]).xyz, vcom[0].xyz, 96) != 0) { bp_bases_free(crs.gh); return BP_E_STATE; }
   RangeProof proof;
+  Projective value{};
   double tp = 0, tv = 0;
   *ok = 1;
   // a proof is a chain of small launches: no event markers around its MSMs
@@ -227,15 +246,29 @@ int range_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const u
       SeededTranscript<Fr> t1(seed_chal);
       SeededRandom<Fr> rng(seed_rand);
       auto a = std::chrono::steady_clock::now();
-      proof = R::prove(ctx, crs, vals, gam, n_bits, t1, rng);
+      proof = single ? R1::prove(ctx, crs, vals[0], gam[0], n_bits, t1, rng) : R::prove(ctx, crs, vals, gam, n_bits, t1, rng);
       auto b = std::chrono::steady_clock::now();
       RangeProof check_proof = proof;
-      if (tamper) check_proof.t_hat = ScalarOps<Fr>::add(check_proof.t_hat, ScalarOps<Fr>::one());
+      if (tamper == 1) check_proof.t_hat = ScalarOps<Fr>::add(check_proof.t_hat, ScalarOps<Fr>::one());
+      if (tamper == 2 && !check_proof.ipa.L.empty()) { check_proof.ipa.L.pop_back(); check_proof.ipa.R.pop_back(); }
+      if (tamper == 3) { check_proof.ipa.L.push_back(proof.a); check_proof.ipa.R.push_back(proof.s); }
       SeededTranscript<Fr> t2(seed_chal);
       SeededRandom<Fr> vrng(seed_rand ^ 0x5EEDull);
+      if (tamper >= 2) {
+        // a proof of the wrong shape is refused before any device work, by both verifiers
+        int refused = 0;
+        try { R::verify_aux(ctx, crs, vcom, n_bits, check_proof, t2, vrng); } catch (const VerificationError&) { refused++; }
+        SeededTranscript<Fr> t3(seed_chal);
+        try { R::verify_aux_stepwise(ctx, crs, vcom, n_bits, check_proof, t3, vrng); } catch (const VerificationError&) { refused++; }
+        if (refused != 2) throw std::runtime_error("malformed proof not refused");
+        *ok = 0;
+        continue;
+      }
       auto c = std::chrono::steady_clock::now();
-      auto msm = R::verify_aux(ctx, crs, vcom, n_bits, check_proof, t2, vrng);
-      bool good = is_zero(msm.execute());  // src/range/aggregate.rs:294-299
+      auto msm = single ? R1::verify_aux(ctx, crs, vcom[0], n_bits, check_proof, t2, vrng)
+                        : R::verify_aux(ctx, crs, vcom, n_bits, check_proof, t2, vrng);
+      value = msm.execute();
+      bool good = is_zero(value);  // src/range/aggregate.rs:294-299, src/range/mod.rs:261-267
       auto d = std::chrono::steady_clock::now();
       if (!good) *ok = 0;
       if (r == 0) {
@@ -257,6 +290,7 @@ int range_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const u
   bp_bases_free(crs.gh);
   *prove_ms = tp / reps;
   *verify_ms = tv / reps;
+  if (out_value) memcpy(out_value, value.xyz, 96);
   memcpy(out_points, proof.a.xyz, 96); memcpy(out_points + 12, proof.s.xyz, 96);
   memcpy(out_points + 24, proof.tt1.xyz, 96); memcpy(out_points + 36, proof.tt2.xyz, 96);
   memcpy(out_scalars, proof.tao_x.l, 32); memcpy(out_scalars + 4, proof.mu.l, 32); memcpy(out_scalars + 8, proof.t_hat.l, 32);
@@ -385,21 +419,24 @@ int bph_range_agg_throughput(int device, int curve, const uint64_t* gx, const ui
 // prove, then verify, `reps` times with identical seeds; averages the wall time of
 // each phase.  ugh_xy = affine u, g, h (3 x 8 u64).  Outputs of the last proof:
 // out_points = A, S, T1, T2 (4 x 12 u64); out_scalars = tao_x, mu, t_hat, a, b
-// (5 x 4 u64); out_lr = log2(N) x (L, R) (24 u64 each).
+// (5 x 4 u64); out_lr = log2(N) x (L, R) (24 u64 each); out_value (may be NULL) = the value of the
+// verifier's deferred MSM on the checked proof.  tamper: 0 none, 1 t_hat + 1, 2 a round dropped,
+// 3 a round appended (2 and 3 must be refused for their shape).  single != 0 (m = 1) drives the
+// single-value types of src/range/mod.rs.
 int bph_range_agg_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx,
                             const uint64_t* hy, const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma,
                             size_t m, unsigned n_bits, uint64_t seed_rand, uint64_t seed_chal, int tamper, int reps,
-                            uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_lr, double* prove_ms,
-                            double* verify_ms, int* ok) {
+                            int single, uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_lr, uint64_t* out_value,
+                            double* prove_ms, double* verify_ms, int* ok) {
   try {
     if (curve == BP_SECP256K1)
       return range_roundtrip<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(ctx, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits,
-                                                                    seed_rand, seed_chal, tamper, reps, out_points,
-                                                                    out_scalars, out_lr, prove_ms, verify_ms, ok);
+                                                                    seed_rand, seed_chal, tamper, reps, single, out_points,
+                                                                    out_scalars, out_lr, out_value, prove_ms, verify_ms, ok);
     if (curve == BP_VESTA)
       return range_roundtrip<VestaFq, VestaFr, BP_VESTA>(ctx, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits, seed_rand,
-                                                        seed_chal, tamper, reps, out_points, out_scalars, out_lr, prove_ms,
-                                                        verify_ms, ok);
+                                                        seed_chal, tamper, reps, single, out_points, out_scalars, out_lr,
+                                                        out_value, prove_ms, verify_ms, ok);
     return BP_E_CURVE;
   } catch (const std::exception&) {
     return BP_E_HIP;
@@ -417,7 +454,8 @@ template <class Fq, class Fr, int CURVE>
 int poly_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uint64_t* h_gen_xy, const uint64_t* coeffs,
                    size_t n_coeffs, size_t n, const uint64_t* r_x, uint64_t seed_rand, uint64_t seed_chal, int tamper,
                    int halo, uint64_t* out_l, uint64_t* out_r, uint64_t* out_ar, uint64_t* out_g, uint64_t* out_commit,
-                   uint64_t* out_eval, double* prove_ms, double* verify_ms, int* ok_verify, int* ok_lazy, int* ok_halo) {
+                   uint64_t* out_eval, double* prove_ms, double* verify_ms, int* ok_verify, int* ok_lazy, int* ok_halo,
+                   uint64_t* halo_out, uint64_t* halo_w) {
   using PC = PolyCommit<Fq, Fr, CURVE>;
   using S = ScalarOps<Fr>;
   typename PC::Crs crs;
@@ -438,16 +476,20 @@ int poly_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const ui
     Todo todo = PC::prove(ctx, crs, st, p, r, t1, rng, proof);
     auto a1 = std::chrono::steady_clock::now();
     auto st_check = st;
-    if (tamper) st_check.evaluation = S::add(st_check.evaluation, S::one());
+    if (tamper == 1) st_check.evaluation = S::add(st_check.evaluation, S::one());
+    PolyProof check_proof = proof;
+    if (tamper == 2 && !check_proof.L.empty()) { check_proof.L.pop_back(); check_proof.R.pop_back(); }   // a round dropped
+    if (tamper == 3) { check_proof.L.push_back(st.commitment); check_proof.R.push_back(st.commitment); }  // a round appended
+    if (tamper == 4) check_proof.R.push_back(st.commitment);                                              // ragged
     SeededTranscript<Fr> t2(seed_chal);
     auto b0 = std::chrono::steady_clock::now();
-    *ok_verify = PC::verify(ctx, crs, st_check, proof, t2) ? 1 : 0;
+    *ok_verify = PC::verify(ctx, crs, st_check, check_proof, t2) ? 1 : 0;
     auto b1 = std::chrono::steady_clock::now();
     *prove_ms = std::chrono::duration<double, std::milli>(a1 - a0).count();
     *verify_ms = std::chrono::duration<double, std::milli>(b1 - b0).count();
     std::vector<Todo> todos;
     SeededTranscript<Fr> t3(seed_chal);
-    *ok_lazy = PC::lazy_verify(ctx, crs, st_check, todo.g, proof, t3, todos) ? 1 : 0;
+    *ok_lazy = PC::lazy_verify(ctx, crs, st_check, todo.g, check_proof, t3, todos) ? 1 : 0;
     size_t k = proof.L.size();
     for (size_t j = 0; j < k; j++) { memcpy(out_l + 12 * j, proof.L[j].xyz, 96); memcpy(out_r + 12 * j, proof.R[j].xyz, 96); }
     memcpy(out_ar, proof.a.l, 32); memcpy(out_ar + 4, proof.r.l, 32);
@@ -479,6 +521,23 @@ int poly_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const ui
       SeededTranscript<Fr> t7(seed_chal + 9999);
       ok = ok && PC::verify(ctx, crs, fst, proof3, t7);
       *ok_halo = ok ? 1 : 0;
+      if (halo_out) {
+        uint64_t* o = halo_out;
+        auto put_proof = [&](const PolyProof& pf) {
+          for (size_t j = 0; j < k; j++) { memcpy(o, pf.L[j].xyz, 96); o += 12; }
+          for (size_t j = 0; j < k; j++) { memcpy(o, pf.R[j].xyz, 96); o += 12; }
+          memcpy(o, pf.a.l, 32); memcpy(o + 4, pf.r.l, 32); o += 8;
+        };
+        put_proof(proof2);
+        memcpy(o, todo2.g.x, 32); memcpy(o + 4, todo2.g.y, 32); o[8] = todo2.g.inf; o += 9;
+        memcpy(o, st2.commitment.xyz, 96); o += 12;
+        memcpy(o, st2.evaluation.l, 32); o += 4;
+        memcpy(o, alpha.l, 32); memcpy(o + 4, x2.l, 32); o += 8;
+        memcpy(o, fst.commitment.xyz, 96); o += 12;
+        memcpy(o, fst.evaluation.l, 32); o += 4;
+        put_proof(proof3);
+      }
+      if (halo_w) memcpy(halo_w, w[0].l, 32 * w.size());
     }
   } catch (...) {
     bp_bases_free(crs.bases);
@@ -496,22 +555,28 @@ extern "C" {
 // statement, prove, verify, lazy_verify, and (halo != 0) the fold of two deferred checks.
 // h_gen_xy = affine h, group generator (2 x 8 u64); r_x = blinder r, evaluation point x.
 // Outputs: L, R (k x 12 u64 each), (a, r), folded generator g (x|y|inf: 9 u64), the
-// commitment (12) and the evaluation (4) of the first statement.
+// commitment (12) and the evaluation (4) of the first statement.  tamper: 0 none, 1 evaluation + 1,
+// 2 a round dropped, 3 a round appended, 4 one more R than L.  With halo != 0, halo_out (may be NULL;
+// 48k + 65 u64) receives, in this order: the second opening (reversed coefficients; transcript seed
+// seed_chal + 7777) as L (12k), R (12k), a, r (8), its folded generator (9), its commitment (12) and
+// evaluation (4); the fold challenges alpha, x (8); the folded statement's commitment (12) and
+// evaluation (4); the opening of the folded statement (seed_chal + 9999) as L, R, a, r; and halo_w (may
+// be NULL; n x 4 u64) the folded witness's coefficients.
 int bph_poly_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_t* gy, const uint64_t* h_gen_xy,
                        const uint64_t* coeffs, size_t n_coeffs, size_t n, const uint64_t* r_x, uint64_t seed_rand,
                        uint64_t seed_chal, int tamper, int halo, uint64_t* out_l, uint64_t* out_r, uint64_t* out_ar,
                        uint64_t* out_g, uint64_t* out_commit, uint64_t* out_eval, double* prove_ms, double* verify_ms,
-                       int* ok_verify, int* ok_lazy, int* ok_halo) {
+                       int* ok_verify, int* ok_lazy, int* ok_halo, uint64_t* halo_out, uint64_t* halo_w) {
   try {
     if (curve == BP_SECP256K1)
       return poly_roundtrip<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(ctx, gx, gy, h_gen_xy, coeffs, n_coeffs, n, r_x, seed_rand,
                                                                    seed_chal, tamper, halo, out_l, out_r, out_ar, out_g,
                                                                    out_commit, out_eval, prove_ms, verify_ms, ok_verify,
-                                                                   ok_lazy, ok_halo);
+                                                                   ok_lazy, ok_halo, halo_out, halo_w);
     if (curve == BP_VESTA)
       return poly_roundtrip<VestaFq, VestaFr, BP_VESTA>(ctx, gx, gy, h_gen_xy, coeffs, n_coeffs, n, r_x, seed_rand, seed_chal,
                                                        tamper, halo, out_l, out_r, out_ar, out_g, out_commit, out_eval,
-                                                       prove_ms, verify_ms, ok_verify, ok_lazy, ok_halo);
+                                                       prove_ms, verify_ms, ok_verify, ok_lazy, ok_halo, halo_out, halo_w);
     return BP_E_CURVE;
   } catch (const std::exception&) {
     return BP_E_HIP;

@@ -149,6 +149,8 @@ struct PolyCommit {
   }
 
   static void replay(const Crs& crs, const PolyProof& proof, Transcript& t, Affine& u, std::vector<Scalar>& ui) {
+    // the reference reads exactly log2(crs.size()) pairs (:129-145, :274-290)
+    checked_rounds(proof.L.size(), proof.R.size(), crs.gs.size());
     u = P::to_affine(P::lower(crs.gen_tab.mul(t.verifier_scalar())));                   // :132-135
     for (size_t j = 0; j < proof.L.size(); j++) {
       Projective lr[2] = {proof.L[j], proof.R[j]};
@@ -162,9 +164,8 @@ struct PolyCommit {
   // poly_commit::verify, src/poly_commit/mod.rs:121-173
   static bool verify(bp_ctx* ctx, const Crs& crs, const Statement& st, const PolyProof& proof, Transcript& t) {
     Affine u; std::vector<Scalar> ui;
-    replay(crs, proof, t, u, ui);
+    try { replay(crs, proof, t, u, ui); } catch (const VerificationError&) { return false; }
     const size_t k = ui.size();
-    if (((size_t)1 << k) != crs.gs.size()) return false;
     std::vector<Scalar> uinv(k);
     for (size_t j = 0; j < k; j++) uinv[j] = S::inv(ui[j]);
     Projective g;  // <h_poly.coeffs(), gs> with the coefficients built and consumed on the device (:152-159)
@@ -180,7 +181,7 @@ struct PolyCommit {
   static bool lazy_verify(bp_ctx* ctx, const Crs& crs, const Statement& st, const Affine& assumption, const PolyProof& proof,
                           Transcript& t, std::vector<Todo>& todos) {
     Affine u; std::vector<Scalar> ui;
-    replay(crs, proof, t, u, ui);
+    try { replay(crs, proof, t, u, ui); } catch (const VerificationError&) { return false; }
     Scalar b = hpoly_evaluate(ui, st.x);                                                // :301
     if (!final_check(ctx, crs, st, proof, u, ui, assumption, b)) return false;
     todos.push_back(Todo{assumption, ui});                                              // :309-313

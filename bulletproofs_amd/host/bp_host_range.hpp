@@ -181,8 +181,7 @@ struct RangeAggregate {
     t.prover_scalars(msg, 3);
     Scalar xe = t.verifier_scalar();
     // the inner-product argument's challenges (src/ipa/mod.rs:116-132)
-    const size_t k = pr.ipa.L.size();
-    if (((size_t)1 << k) != n) throw std::invalid_argument("proof of another size");
+    const size_t k = checked_rounds(pr.ipa.L.size(), pr.ipa.R.size(), n);
     std::vector<Scalar> xs(k), xinv(k);
     for (size_t j = 0; j < k; j++) {
       Projective lr[2] = {pr.ipa.L[j], pr.ipa.R[j]};
@@ -254,6 +253,8 @@ struct RangeAggregate {
   static M verify_aux_stepwise(bp_ctx* ctx, const Crs& crs, const std::vector<Projective>& v_commit, unsigned n_bits,
                       const RangeProof& pr, Transcript& t, RandomSource& rng) {
     const size_t m = v_commit.size(), n = (size_t)n_bits * m;
+    if (n != crs.n) throw std::invalid_argument("CRS registered for another size");
+    checked_rounds(pr.ipa.L.size(), pr.ipa.R.size(), n);
     const Scalar one = S::one();
     Projective as[2] = {pr.a, pr.s};
     t.prover_points(as, 2);
@@ -325,6 +326,41 @@ struct RangeAggregate {
     msm.scale_elems(hs, y_inv_pows);
     msm.upsert(P::to_affine(g_check), rng.scalar());                           // :278-279
     return msm;
+  }
+};
+
+// Single-value range proof (Bulletproofs section 4.1-4.2; src/range/mod.rs:26-268; the shape of
+// benches/range_bench.rs, n_bits = 8..64).  Every expression of that file is the one-value case of
+// the aggregated protocol, term by term: the r-polynomial's two_vec * z^2 (:108) is z^(2+j) 2^i at
+// j = 0 (src/range/aggregate.rs:109-114), tao_x's z^2 * gamma (:129) is the one-term sigma_summand
+// (aggregate.rs:136-139), delta's z^3 * sum(two_vec) (:198-200) is aggregate.rs:209-215 with one
+// power of z, and statement.v.mul(z^2) (:203) is the one-point MSM of aggregate.rs:226.  The
+// same device work therefore serves both; this type fixes m = 1 and keeps the single-value
+// signatures (one value, one blinder, one commitment).
+template <class Fq, class Fr, int CURVE>
+struct Range {
+  using A = RangeAggregate<Fq, Fr, CURVE>;
+  using Crs = typename A::Crs;
+  using M = typename A::M;
+  // Statement::new, src/range/types.rs:62-68: V = v g + gamma h
+  static Projective statement(const Crs& crs, uint64_t v, const Scalar& gamma) {
+    using P = PointOps<Fq, Fr>;
+    return P::lower(hx_add<Fq>(crs.g_tab.mul(A::from_u64(v)), crs.h_tab.mul(gamma)));
+  }
+  // range::prove, src/range/mod.rs:26-159
+  static RangeProof prove(bp_ctx* ctx, const Crs& crs, uint64_t v, const Scalar& gamma, unsigned n_bits, Transcript& t,
+                          RandomSource& rng) {
+    return A::prove(ctx, crs, std::vector<uint64_t>{v}, std::vector<Scalar>{gamma}, n_bits, t, rng);
+  }
+  // range::verify_aux, src/range/mod.rs:162-249
+  static M verify_aux(bp_ctx* ctx, const Crs& crs, const Projective& v_commit, unsigned n_bits, const RangeProof& pr,
+                      Transcript& t, RandomSource& rng) {
+    return A::verify_aux(ctx, crs, std::vector<Projective>{v_commit}, n_bits, pr, t, rng);
+  }
+  // range::verify, src/range/mod.rs:252-268
+  static bool verify(bp_ctx* ctx, const Crs& crs, const Projective& v_commit, unsigned n_bits, const RangeProof& pr,
+                     Transcript& t, RandomSource& rng) {
+    return is_zero(verify_aux(ctx, crs, v_commit, n_bits, pr, t, rng).execute());
   }
 };
 

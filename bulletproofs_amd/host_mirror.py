@@ -59,14 +59,16 @@ def ipa_roundtrip(ctx: Context, curve, gs, hs, u_xy, a, b, n_proofs=1, seed=1, t
 
 
 hlib.bph_range_agg_roundtrip.restype = ci
-hlib.bph_range_agg_roundtrip.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint64, C.c_uint64, ci, ci,
-                                         vp, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]
+hlib.bph_range_agg_roundtrip.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint64, C.c_uint64, ci, ci, ci,
+                                         vp, vp, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]
 
 
 def range_aggregate_roundtrip(ctx: Context, curve, gs, hs, ugh_xy, values, gamma, n_bits, seed_rand=1, seed_chal=2,
-                              tamper=False, reps=1):
+                              tamper=False, reps=1, single=False):
     """aggregated range proof (src/range/aggregate.rs): prove + verify through the GPU path.
-    ugh_xy: (3, 8) uint64 = affine u, g, h.  values: m integers < 2^n_bits."""
+    ugh_xy: (3, 8) uint64 = affine u, g, h.  values: m integers < 2^n_bits.  tamper: False/0 none,
+    True/1 t_hat + 1, 2 a round dropped, 3 a round appended.  single=True (one value) drives the
+    single-value types of src/range/mod.rs.  `value` is the verifier's deferred MSM evaluated."""
     gx, gy, _ = _pts(gs)
     hx, hy, _ = _pts(hs)
     values = np.ascontiguousarray(values, dtype=np.uint64)
@@ -79,14 +81,16 @@ def range_aggregate_roundtrip(ctx: Context, curve, gs, hs, ugh_xy, values, gamma
     pts = np.zeros((4, 12), dtype=np.uint64)
     sc = np.zeros((5, 4), dtype=np.uint64)
     lr = np.zeros((max(k, 1), 24), dtype=np.uint64)
+    value = np.zeros(12, dtype=np.uint64)
     tp, tv, ok = C.c_double(), C.c_double(), ci()
     rc = hlib.bph_range_agg_roundtrip(ctx.h, curve, _p(gx), _p(gy), _p(hx), _p(hy), _p(ugh_xy), _p(values), _p(gamma), m,
-                                      n_bits, seed_rand, seed_chal, int(tamper), reps, _p(pts), _p(sc), _p(lr),
-                                      C.byref(tp), C.byref(tv), C.byref(ok))
+                                      n_bits, seed_rand, seed_chal, int(tamper), reps, int(single), _p(pts), _p(sc), _p(lr),
+                                      _p(value), C.byref(tp), C.byref(tv), C.byref(ok))
     if rc:
         raise RuntimeError(f"bph_range_agg_roundtrip rc={rc}")
     return dict(A=pts[0], S=pts[1], TT1=pts[2], TT2=pts[3], tao_x=sc[0], mu=sc[1], t_hat=sc[2], a=sc[3], b=sc[4],
-                L=lr[:k, :12], R=lr[:k, 12:], prove_ms=tp.value, verify_ms=tv.value, ok=bool(ok.value))
+                L=lr[:k, :12], R=lr[:k, 12:], points=pts, scalars=sc, lr=lr, value=value, prove_ms=tp.value,
+                verify_ms=tv.value, ok=bool(ok.value))
 
 
 hlib.bph_range_agg_throughput.restype = ci
@@ -117,7 +121,8 @@ def range_aggregate_throughput(device, curve, gs, hs, ugh_xy, values, gamma, n_b
 
 hlib.bph_poly_roundtrip.restype = ci
 hlib.bph_poly_roundtrip.argtypes = [vp, ci, vp, vp, vp, vp, sz, sz, vp, C.c_uint64, C.c_uint64, ci, ci, vp, vp, vp, vp, vp, vp,
-                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci),
+                                    vp, vp]
 
 
 def poly_commit_roundtrip(ctx: Context, curve, gs, h_gen_xy, coeffs, r, x, seed_rand=1, seed_chal=2, tamper=False, halo=True):
@@ -139,13 +144,30 @@ def poly_commit_roundtrip(ctx: Context, curve, gs, h_gen_xy, coeffs, r, x, seed_
     ev = np.zeros(4, dtype=np.uint64)
     tp, tv = C.c_double(), C.c_double()
     okv, okl, okh = ci(), ci(), ci()
+    want_halo = bool(halo) and not tamper
+    ho = np.zeros(48 * k + 65, dtype=np.uint64) if want_halo else None
+    hw = np.zeros((n, 4), dtype=np.uint64) if want_halo else None
     rc = hlib.bph_poly_roundtrip(ctx.h, curve, _p(gx), _p(gy), _p(h_gen_xy), _p(coeffs), coeffs.shape[0], n, _p(rx), seed_rand,
                                  seed_chal, int(tamper), int(halo), _p(L), _p(R), _p(ar), _p(g), _p(com), _p(ev),
-                                 C.byref(tp), C.byref(tv), C.byref(okv), C.byref(okl), C.byref(okh))
+                                 C.byref(tp), C.byref(tv), C.byref(okv), C.byref(okl), C.byref(okh), _p(ho), _p(hw))
     if rc:
         raise RuntimeError(f"bph_poly_roundtrip rc={rc}")
-    return dict(L=L[:k], R=R[:k], a=ar[0], r=ar[1], g=g, commitment=com, evaluation=ev, prove_ms=tp.value,
-                verify_ms=tv.value, verify_ok=bool(okv.value), lazy_ok=bool(okl.value), halo_ok=bool(okh.value))
+    res = dict(L=L[:k], R=R[:k], a=ar[0], r=ar[1], g=g, commitment=com, evaluation=ev, prove_ms=tp.value,
+               verify_ms=tv.value, verify_ok=bool(okv.value), lazy_ok=bool(okl.value), halo_ok=bool(okh.value))
+    if want_halo:
+        pos = [0]
+
+        def take(cnt, shape=None):
+            v = ho[pos[0]:pos[0] + cnt]
+            pos[0] += cnt
+            return v if shape is None else v.reshape(shape)
+
+        second = dict(L=take(12 * k, (k, 12)), R=take(12 * k, (k, 12)), a=take(4), r=take(4), g=take(9), commitment=take(12),
+                      evaluation=take(4))
+        folded = dict(alpha=take(4), x=take(4), commitment=take(12), evaluation=take(4))
+        folded.update(L=take(12 * k, (k, 12)), R=take(12 * k, (k, 12)), a=take(4), r=take(4), witness=hw)
+        res.update(second=second, folded=folded)
+    return res
 
 
 def range_bench_inputs(ctx: Context, m, n_bits, seed):

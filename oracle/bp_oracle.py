@@ -627,6 +627,57 @@ def range_aggregate_prove(c: Curve, gs, hs, u, g, h, values, gammas, n_bits, ran
     return dict(A=A, S=S, TT1=TT1, TT2=TT2, tao_x=tao_x, mu=mu, t_hat=t_hat, L=Ls, R=Rs, a=af[0], b=bf[0])
 
 
+def range_prove(c: Curve, gs, hs, u, g, h, v, gamma, n_bits, rand_seed, chal_seed):
+    """Single-value range proof, src/range/mod.rs:26-159, written from that file's own
+    expressions (two_vec scaled by z^2, tao_x with z^2 * gamma).  Same stand-ins for
+    randomness and challenges as range_aggregate_prove."""
+    mod = c.n
+    n = n_bits
+    rnd = SplitMix64(rand_seed)
+    counter = [0]
+
+    def chal():
+        val = SplitMix64(chal_seed + counter[0]).field(mod)
+        counter[0] += 1
+        return val
+
+    gs, hs = list(gs[:n]), list(hs[:n])
+    two_vec = [pow(2, i, mod) for i in range(n)]                           # :46-50
+    a_l = [(v >> i) & 1 for i in range(n)]                                 # :52-56
+    a_r = [(b - 1) % mod for b in a_l]                                     # :58
+    alpha, rho = rnd.field(mod), rnd.field(mod)                            # :60-61
+    s_l = [rnd.field(mod) for _ in range(n)]                               # :62-64
+    s_r = [rnd.field(mod) for _ in range(n)]                               # :65-67
+    msm = msm_pippenger if n > 16 else msm_naive
+    A = add(scalar_mul(alpha, h, c), msm(gs + hs, a_l + a_r, c), c)        # :77
+    S = add(scalar_mul(rho, h, c), msm(gs + hs, s_l + s_r, c), c)          # :78
+    y, z = chal(), chal()                                                  # :82
+    y_vec = powers(y, n, mod)                                              # :83-86
+    l0 = [(a - z) % mod for a in a_l]                                      # :90-92
+    r0 = [(yy * ((ar + z) % mod) + z * z * tw) % mod for yy, ar, tw in zip(y_vec, a_r, two_vec)]   # :100-109
+    r1 = hadamard(y_vec, s_r, mod)                                         # :110
+    tao1, tao2 = rnd.field(mod), rnd.field(mod)                            # :115-116
+    t1 = (inner_product(l0, r1, mod) + inner_product(s_l, r0, mod)) % mod  # :119
+    t2 = inner_product(s_l, r1, mod)
+    TT1 = add(scalar_mul(t1, g, c), scalar_mul(tao1, h, c), c)             # :120
+    TT2 = add(scalar_mul(t2, g, c), scalar_mul(tao2, h, c), c)             # :121
+    x = chal()                                                             # :127
+    tao_x = (tao2 * x * x + tao1 * x + z * z * gamma) % mod                # :129
+    mu = (alpha + rho * x) % mod                                           # :130
+    l = [(a + b * x) % mod for a, b in zip(l0, s_l)]                       # :131
+    r = [(a + b * x) % mod for a, b in zip(r0, r1)]                        # :132
+    t_hat = inner_product(l, r, mod)
+    hs_p = scale_points(hs, hs_prime_scalars(n, y, mod), c)                # :136-141
+    xe = chal()                                                            # src/ipa/extended.rs:24
+    u2 = scalar_mul(xe, u, c)
+    k = n.bit_length() - 1
+    chs = [chal() for _ in range(k)]
+    rounds, (gf, hf, af, bf) = ipa_prove(BULLETPROOF, gs, hs_p, l, r, chs, c, msm)
+    Ls = [add(rd["L"], scalar_mul(rd["cL"], u2, c), c) for rd in rounds]
+    Rs = [add(rd["R"], scalar_mul(rd["cR"], u2, c), c) for rd in rounds]
+    return dict(A=A, S=S, TT1=TT1, TT2=TT2, tao_x=tao_x, mu=mu, t_hat=t_hat, L=Ls, R=Rs, a=af[0], b=bf[0])
+
+
 # ---- polynomial commitment (src/poly_commit) ---------------------------------------------
 
 def poly_commit_statement(c: Curve, gs, h, coeffs, r, x):

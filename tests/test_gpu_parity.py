@@ -811,3 +811,31 @@ def test_msm_window_tables(ctx, coracle, c, n):
     if n > 10:
         assert np.array_equal(b.msm(K[2:9], offset=2, n=7), coracle.msm(c.id, (px[2:9], py[2:9], inf[2:9]), K[2:9], 8))
     b.free()
+
+
+@pytest.mark.parametrize("n", [1, 5, 64])
+def test_window_tables_on_a_fresh_context(coracle, n):
+    """the table path's per-slice histograms need a buffer that does not shrink with n: a context
+    whose workspace has never grown (no earlier large MSM) runs register -> precompute -> msm, and a
+    two-sum IPA session of 4 generators over the same tables, against the oracle"""
+    import bulletproofs_amd as bp
+
+    c = o.SECP256K1
+    fresh = bp.Context(0)
+    try:
+        px, py = seeded_points(coracle, c, max(n, 8), 91 + n, 17)
+        _, K = random_scalars(c, n, 3 * n + 1)
+        b = fresh.register_bases(c.id, (px, py, None)).precompute()
+        assert np.array_equal(b.msm(K, n=n), coracle.msm(c.id, (px[:n], py[:n], None), K, 4))
+        ints_a, A = random_scalars(c, 4, 11)
+        ints_b, B = random_scalars(c, 4, 12)
+        s = fresh.ipa_begin_resident(b, bp.IPA_BULLETPROOF, 0, 4, A, B)
+        L, R, cl, cr = s.round_lr()
+        pts = o.unpack_points(px[:8], py[:8], np.zeros(8, dtype=np.uint8), c)
+        eL, eR, ecl, ecr = o.ipa_round_lr(o.BULLETPROOF, pts[:4], pts[4:8], ints_a, ints_b, c)
+        assert xyz_to_affine(L, c) == eL and xyz_to_affine(R, c) == eR
+        assert o.unpack_field(cl, c.n)[0] == ecl and o.unpack_field(cr, c.n)[0] == ecr
+        s.free()
+        b.free()
+    finally:
+        fresh.close()

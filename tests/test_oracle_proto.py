@@ -165,3 +165,27 @@ def test_fold_generators_shared_doublings_matches_kernel_oracle(coracle):
     # second-round L uses the folded generators: checked through the Python replay above; here the final scalars
     rounds, (_, _, af, bf) = o.ipa_prove(o.BULLETPROOF, g, h, a, b, [x, chal(3, 1, c.n)], c)
     assert o.unpack_field(got["a"], c.n) == af and o.unpack_field(got["b"], c.n) == bf
+
+
+@pytest.mark.parametrize("n_bits", [8, 64])
+def test_single_value_range_proof_is_the_one_value_aggregate(coracle, n_bits):
+    """src/range/mod.rs:26-159 restated from its own expressions (Python) equals the C oracle's
+    aggregated prover at m = 1, message by message: the single-value protocol (benches/range_bench.rs,
+    n_bits = 64) is driven through the aggregated code path"""
+    c = o.SECP256K1
+    rng = o.SplitMix64(4000 + n_bits)
+    gs = o.gen_points_arith(n_bits, rng.field(c.n), rng.field(c.n), c)
+    hs = o.gen_points_arith(n_bits, rng.field(c.n), rng.field(c.n), c)
+    u, g, h = (o.scalar_mul(rng.field(c.n), c.g, c) for _ in range(3))
+    v = rng.next() & ((1 << n_bits) - 1)
+    gamma = rng.field(c.n)
+    exp = o.range_prove(c, gs, hs, u, g, h, v, gamma, n_bits, 11, 22)
+    ugh = np.stack([xy8(P, c) for P in (u, g, h)])
+    got = coracle.range_agg_prove(c.id, o.pack_points(gs, c), o.pack_points(hs, c), ugh, [v], o.pack_field([gamma], c.n),
+                                  n_bits, 11, 22, threads=2)
+    for key in ("A", "S", "TT1", "TT2"):
+        assert xyz_to_affine(got[key], c) == exp[key], key
+    for key in ("tao_x", "mu", "t_hat", "a", "b"):
+        assert o.unpack_field(got[key], c.n)[0] == exp[key], key
+    for j in range(len(exp["L"])):
+        assert xyz_to_affine(got["L"][j], c) == exp["L"][j] and xyz_to_affine(got["R"][j], c) == exp["R"][j]
