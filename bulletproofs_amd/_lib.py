@@ -90,6 +90,7 @@ SIGNATURES = {
     "bp_scale_points": (ci, [vp, ci, vp, vp, vp, vp, sz, vp, vp, vp]),
     "bp_normalize_batch": (ci, [vp, ci, vp, sz, vp, vp, vp]),
     "bp_inner_product_dev": (ci, [vp, ci, vp, vp, sz, vp]),
+    "bp_inner_product_dev_noalloc": (ci, [vp, ci, vp, vp, sz, vp]),
     "bp_fold_scalars_dev": (ci, [vp, ci, vp, vp, sz, vp, vp, vp]),
     "bp_fold_generators_dev": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
     "bp_s_vector_dev": (ci, [vp, ci, vp, vp, sz, vp]),

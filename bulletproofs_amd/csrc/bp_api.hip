@@ -104,7 +104,15 @@ struct bp_ctx {
   // vector polynomials left on the device by bp_range_agg_poly for bp_range_agg_eval (S_RANGE)
   size_t range_n = 0;
   int range_curve = -1;
+  // this device's copy of the file-scope scratch array of bp_inner_product_dev_noalloc (set by bp_init)
+  u32* static_scratch = nullptr;
 };
+
+// Scratch of bp_inner_product_dev_noalloc: the per-block partial sums (kDotBlocks field elements,
+// 32 KiB).  Every GPU the library runs on holds its own copy at its own address until the process
+// ends; host code reaches it only through the pointer bp_init obtains with hipGetSymbolAddress
+// while that GPU is current (the name itself is a host-side stand-in, not a device address).
+static __device__ __align__(256) u32 scratch[(size_t)kDotBlocks * 8];
 
 struct bp_bases {
   bp_ctx* ctx;
@@ -399,6 +407,15 @@ int bp_init(int device, bp_ctx** out) {
       return BP_E_HIP;
     }
   }
+  // address of this device's copy of the static scratch array (the device is current: hipSetDevice above)
+  {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
+      bp_shutdown(c);
+      return BP_E_HIP;
+    }
+    c->static_scratch = (u32*)p;
+  }
   *out = c;
   return BP_OK;
 }
@@ -678,6 +695,24 @@ int bp_inner_product_dev(bp_ctx* ctx, int curve, const uint64_t* d_a, const uint
     return BP_OK;
   }
   return dot_dev(ctx, curve, (const u32*)d_a, (const u32*)d_b, n, out);
+}
+
+int bp_inner_product_dev_noalloc(bp_ctx* ctx, int curve, const uint64_t* d_a, const uint64_t* d_b, size_t n,
+                                 uint64_t* d_out) {
+  if (!ctx || !d_out || (n && (!d_a || !d_b))) return fail(ctx, BP_E_ARG, "bp_inner_product_dev_noalloc: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  if (n > BP_NOALLOC_MAX_N) return fail(ctx, BP_E_ARG, "bp_inner_product_dev_noalloc: n exceeds BP_NOALLOC_MAX_N (2^28)");
+  Guard g(ctx);
+  if (!ctx->static_scratch) return fail(ctx, BP_E_STATE, "bp_inner_product_dev_noalloc: scratch address unknown");
+  if (n == 0) {
+    HIPCHK(ctx, hipMemsetAsync(d_out, 0, 32, ctx->stream));
+    return BP_OK;
+  }
+  // the partial sums of blocks [0, blocks) are all written before they are read, so the array
+  // needs no clearing between calls; the same two kernels as bp_inner_product_dev
+  hipError_t e = launch_inner_product(curve, (const u32*)d_a, (const u32*)d_b, n, ctx->static_scratch, (u32*)d_out, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "bp_inner_product_dev_noalloc", e);
+  return BP_OK;
 }
 
 int bp_inner_product(bp_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]) {
