@@ -13,13 +13,43 @@
 
 namespace bp {
 
-template <class Fq_, class Fr_>
+// Fq is the field the kernels compute in, FqIn the form coordinates have at the library's
+// boundary (arkworks' Montgomery form).  They differ for Secp256k1P, the curve as the MSM
+// pipeline sees it: coordinates are converted to plain residues once, where the points are
+// packed, because p = 2^256 - 2^32 - 977 reduces a plain product by folding (72 multiply-
+// accumulates per field product instead of 88; see fe_mul_dev_Secp256k1FqP), and the window
+// sums are converted back where they leave the pipeline.
+template <class Fq_, class Fr_, class FqIn_ = Fq_>
 struct CurveT {
   using Fq = Fq_;
   using Fr = Fr_;
+  using FqIn = FqIn_;
+  static constexpr bool kConverts = !__is_same(Fq_, FqIn_);
 };
-using Secp256k1 = CurveT<Secp256k1Fq, Secp256k1Fr>;
-using Vesta = CurveT<VestaFq, VestaFr>;
+using Secp256k1P = CurveT<Secp256k1FqP, Secp256k1Fr, Secp256k1Fq>;
+// the curves at the boundary; Pipeline = the type the MSM pipeline computes on
+struct Secp256k1 : CurveT<Secp256k1Fq, Secp256k1Fr> {
+  using Pipeline = Secp256k1P;
+};
+struct Vesta : CurveT<VestaFq, VestaFr> {
+  using Pipeline = Vesta;
+};
+
+// boundary form -> the form C's kernels compute in, and back
+template <class C>
+BP_DEV Fe fe_import(const Fe& a) {
+  if constexpr (C::kConverts)
+    return fe_from_mont<typename C::FqIn>(a);
+  else
+    return a;
+}
+template <class C>
+BP_DEV Fe fe_export(const Fe& a) {
+  if constexpr (C::kConverts)
+    return fe_to_mont<typename C::FqIn>(a);
+  else
+    return a;
+}
 
 struct Xyzz {
   Fe x, y, zz, zzz;

@@ -148,9 +148,10 @@ __global__ __launch_bounds__(256) void k_window_tables(const u32* __restrict__ p
       for (int k = 0; k < c; k++) acc = jac_dbl<F>(acc);
     Fe x = fe_zero(), y = fe_zero();
     if (!inf) jac_to_affine<F>(acc, x, y);  // never the identity: the group order is an odd prime
+    // the records are read by the MSM pipeline as packed points: in its form (see CurveT)
     u32* rec = table + ((size_t)w * n + i) * 16;
-    fe_store(rec, x);
-    fe_store(rec + 8, y);
+    fe_store(rec, fe_import<typename C::Pipeline>(x));
+    fe_store(rec + 8, fe_import<typename C::Pipeline>(y));
   }
 }
 

@@ -164,6 +164,68 @@ BP_DEV Fe fe_mul_portable(const Fe& a, const Fe& b) {
   return fe_reduce_once<F>(r, t[8]);
 }
 
+// ---- secp256k1 base field on plain residues (Secp256k1FqP) ---------------------------------
+// p = 2^256 - c, c = 2^32 + 977: a value r + 2^256 t (r eight limbs, t < 2^40) is congruent to
+// r + c t.  Adds c t, folds the carry that may leave limb 7 the same way, and subtracts p once
+// if needed: the result is the canonical residue.
+BP_DEV Fe fe_plain_secp_finish(const Fe& r, uint64_t t) {
+  // c t = 977 t + 2^32 t with t < 2^38: 977 t = w_hi 2^32 + w_lo (w_hi < 2^16)
+  const uint32_t t_lo = (uint32_t)t, t_hi = (uint32_t)(t >> 32);
+  const uint64_t w = (uint64_t)t_lo * 977u;
+  const uint32_t w_lo = (uint32_t)w, w_hi = (uint32_t)(w >> 32) + t_hi * 977u;
+  Fe u = r;
+  uint32_t c = 0, c2 = 0;
+  u.v[0] = __builtin_addc(r.v[0], w_lo, 0u, &c);
+  u.v[1] = __builtin_addc(r.v[1], w_hi, c, &c);
+  u.v[1] = __builtin_addc(u.v[1], t_lo, 0u, &c2);
+  u.v[2] = __builtin_addc(r.v[2], t_hi + c2, c, &c);
+  // c t has about 70 bits, so a carry out of limb 2 has probability about 2^-27 and a value in
+  // [p, 2^256) needs limbs 2..7 all ones (2^-192): both go to a branch that is practically never
+  // taken instead of a carry chain and a selection on every product
+  const uint32_t top = u.v[2] & u.v[3] & u.v[4] & u.v[5] & u.v[6] & u.v[7];
+  if (__builtin_expect((c | (top == 0xffffffffu)) != 0, 0)) {
+#pragma unroll
+    for (int i = 3; i < 8; i++) u.v[i] = __builtin_addc(u.v[i], 0u, c, &c);
+    // value = u + 2^256 c (c is 0 or 1) = u + c (2^32 + 977) mod p; s2 = u + (2^32 + 977)
+    Fe s2;
+    uint32_t q = 0;
+    s2.v[0] = __builtin_addc(u.v[0], 977u, q, &q);
+    s2.v[1] = __builtin_addc(u.v[1], 1u, q, &q);
+#pragma unroll
+    for (int i = 2; i < 8; i++) s2.v[i] = __builtin_addc(u.v[i], 0u, q, &q);
+    u = fe_select((c | q) != 0, s2, u);
+  }
+  return u;
+}
+
+// portable plain multiply: schoolbook product, then the same fold (host builds; reference for
+// the device form)
+BP_DEV Fe fe_mul_plain_secp_portable(const Fe& a, const Fe& b) {
+  uint32_t t[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      uint64_t x = (uint64_t)a.v[j] * b.v[i] + t[i + j] + c;
+      t[i + j] = (uint32_t)x;
+      c = x >> 32;
+    }
+    t[i + 8] = (uint32_t)c;
+  }
+  Fe r;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    acc += (uint64_t)t[k] + (uint64_t)t[8 + k] * 977u + (k ? t[8 + k - 1] : 0u);
+    r.v[k] = (uint32_t)acc;
+    acc >>= 32;
+  }
+  return fe_plain_secp_finish(r, acc + t[15]);
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // Device form: product scanning (column by column) in straight-line inline asm,
 // generated per field by tools/gen_fe_mul.py.  A column's partial products are
@@ -180,6 +242,10 @@ BP_DEV Fe fe_mul(const Fe& a, const Fe& b) {
 template <class F>
 BP_DEV Fe fe_mul(const Fe& a, const Fe& b) {
   return fe_mul_portable<F>(a, b);
+}
+template <>
+BP_DEV Fe fe_mul<Secp256k1FqP>(const Fe& a, const Fe& b) {
+  return fe_mul_plain_secp_portable(a, b);
 }
 #endif
 

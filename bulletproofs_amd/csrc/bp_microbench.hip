@@ -50,6 +50,28 @@ __global__ __launch_bounds__(128) void k_mb_jdbl(int iters, u32* __restrict__ io
   if (a.x.v[0] == 0x12345 && a.y.v[3] == 0x54321) fe_store(io, a.x);
 }
 
+// Self-check of the plain secp256k1 multiply: the straight-line device form against the portable
+// form on a chain of products; io[0] receives the number of lanes that disagreed.
+__global__ __launch_bounds__(256) void k_mb_mul_check(int iters, u32* __restrict__ io) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fe x = fe_load(io + (8 + (t & 511)) * 8), y = fe_load(io + (8 + ((t + 1) & 511)) * 8);
+  if ((t & 3) == 1) { for (int i = 0; i < 8; i++) x.v[i] = 0xffffffffu; }   // non-canonical, all ones
+  if ((t & 3) == 2) { for (int i = 0; i < 8; i++) y.v[i] = Secp256k1FqP::mod(i); y.v[0] -= 1; }  // p - 1
+  bool bad = false;
+  for (int i = 0; i < iters; i++) {
+    Fe d = fe_mul<Secp256k1FqP>(x, y), p = fe_mul_plain_secp_portable(x, y);
+    bad |= !fe_eq(d, p);
+    // canonical: d < p
+    uint32_t bw = 0;
+    for (int k = 0; k < 8; k++) (void)__builtin_subc(d.v[k], Secp256k1FqP::mod(k), bw, &bw);
+    bad |= bw == 0;
+    x = y;
+    y = d;
+    y.v[0] ^= (uint32_t)i;  // leaves the canonical range now and then: inputs need not be reduced
+  }
+  if (bad) atomicAdd(io, 1u);
+}
+
 // Reads every 64-byte record of a table exactly once, in a scattered order (lane t reads
 // record t*mult mod records, mult odd), with the four 16-byte loads per lane that the MSM
 // accumulation kernel uses for its point gathers: a known byte count in that access
@@ -78,6 +100,9 @@ hipError_t launch_microbench(int id, int blocks, int iters, u32* io, hipStream_t
     case 2: hipLaunchKernelGGL(k_mb_madd<F>, dim3(blocks), dim3(128), 0, st, iters, io); break;
     case 3: hipLaunchKernelGGL(k_mb_jdbl<F>, dim3(blocks), dim3(128), 0, st, iters, io); break;
     case 4: hipLaunchKernelGGL(k_mb_mul<VestaFq>, dim3(blocks), dim3(256), 0, st, iters, io); break;
+    case 6: hipLaunchKernelGGL(k_mb_mul<Secp256k1FqP>, dim3(blocks), dim3(256), 0, st, iters, io); break;
+    case 7: hipLaunchKernelGGL(k_mb_madd<Secp256k1FqP>, dim3(blocks), dim3(128), 0, st, iters, io); break;
+    case 8: hipLaunchKernelGGL(k_mb_mul_check, dim3(blocks), dim3(256), 0, st, iters, io); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -26,10 +26,11 @@
 
 namespace bp {
 
+// C = the curve as the pipeline computes on it (secp256k1: plain residues, see CurveT)
 #define DISPATCH_CURVE(curve, STMT)              \
   switch (curve) {                               \
     case BP_SECP256K1: {                         \
-      using C = Secp256k1;                       \
+      using C = Secp256k1P;                      \
       constexpr int kBits = 256;                 \
       (void)kBits;                               \
       STMT;                                      \
@@ -290,8 +291,8 @@ __global__ __launch_bounds__(256) void k_digits(const u32* __restrict__ s0, cons
       px = sel.extra_xy[i - n01];
       py = px + 8;
     }
-    fe_store(packed + i * 16, fe_load(px));
-    fe_store(packed + i * 16 + 8, fe_load(py));
+    fe_store(packed + i * 16, fe_import<C>(fe_load(px)));
+    fe_store(packed + i * 16 + 8, fe_import<C>(fe_load(py)));
   }
   const u32* sp = i < n0 ? s0 + i * 8 : s1 + (i - n0) * 8;
   if (is_extra) sp = sel.extra_s[i - n01];
@@ -442,15 +443,17 @@ __global__ __launch_bounds__(1024) void k_small_front(
       }
     }
     if (grp != g) continue;
-    if (w == 0) {
+    // every point is packed (and brought into the pipeline's form) by one block of its group:
+    // spread over the group's window blocks, so that no block has more than its share to convert
+    if ((u32)(i % (size_t)group_windows) == w) {
       const u32* px = second ? x1 + (i - n0) * 8 : x0 + i * 8;
       const u32* py = second ? y1 + (i - n0) * 8 : y0 + i * 8;
       if (is_extra) {
         px = sel.extra_xy[i - n01];
         py = px + 8;
       }
-      fe_store(packed + i * 16, fe_load(px));
-      fe_store(packed + i * 16 + 8, fe_load(py));
+      fe_store(packed + i * 16, fe_import<C>(fe_load(px)));
+      fe_store(packed + i * 16 + 8, fe_import<C>(fe_load(py)));
     }
     const u32* sp = second ? s1 + (i - n0) * 8 : s0 + i * 8;
     if (is_extra) sp = sel.extra_s[i - n01];
@@ -599,15 +602,15 @@ __global__ __launch_bounds__(1024) void k_mid_count(
     if (i >= n) continue;
     const bool is_extra = i >= n01, second = i >= n0;
     const u32 grp = digit_group_of(sel, i, n0, n01);
-    if (w == 0 && !tab) {
+    if ((u32)(i % (size_t)gridDim.y) == w && !tab) {  // packed once, spread over the window blocks
       const u32* px = second ? x1 + (i - n0) * 8 : x0 + i * 8;
       const u32* py = second ? y1 + (i - n0) * 8 : y0 + i * 8;
       if (is_extra) {
         px = sel.extra_xy[i - n01];
         py = px + 8;
       }
-      fe_store(packed + i * 16, fe_load(px));
-      fe_store(packed + i * 16 + 8, fe_load(py));
+      fe_store(packed + i * 16, fe_import<C>(fe_load(px)));
+      fe_store(packed + i * 16 + 8, fe_import<C>(fe_load(py)));
     }
     const u32* sp = second ? s1 + (i - n0) * 8 : s0 + i * 8;
     if (is_extra) sp = sel.extra_s[i - n01];
@@ -798,8 +801,8 @@ __global__ __launch_bounds__(1024) void k_two_digits(const u32* __restrict__ s0,
         py = px + 8;
         sp = sel.extra_s[ii - n01];
       }
-      fe_store(packed + ii * 16, fe_load(px));
-      fe_store(packed + ii * 16 + 8, fe_load(py));
+      fe_store(packed + ii * 16, fe_import<C>(fe_load(px)));
+      fe_store(packed + ii * 16 + 8, fe_import<C>(fe_load(py)));
       is_inf = is_extra ? false : (second ? (inf1 && inf1[ii - n0]) : (inf0 && inf0[ii]));
       k = fe_from_mont<Fr>(fe_load(sp));
       // |k| <= r/2: use r - k with the point negated when that is the smaller value
@@ -1050,6 +1053,17 @@ BP_DEV Xyzz xyzz_load_aos(const u32* p32) {
   p.zz = fe_load(p32 + 16);
   p.zzz = fe_load(p32 + 24);
   return p;
+}
+
+// a point that leaves the pipeline: coordinates back to the boundary form (see CurveT)
+template <class C>
+BP_DEV Xyzz xyzz_export(const Xyzz& p) {
+  Xyzz r;
+  r.x = fe_export<C>(p.x);
+  r.y = fe_export<C>(p.y);
+  r.zz = fe_export<C>(p.zz);
+  r.zzz = fe_export<C>(p.zzz);
+  return r;
 }
 
 // Work is cut into chunks of at most `chunk` sorted entries that never cross a
@@ -1433,7 +1447,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish_tree(const u32* __restric
 // log2(NB) - 1 steps of one addition each.  Then V = sum_b 2^b S_b + NB * B_{NB-1}.
 // One block; buckets base .. base + nb - 1 of an SoA array with plane stride nbt, nb a power
 // of two in 2..256; the value, doubled post_dbl times, goes to out (XYZZ, 32 words).
-template <class C>
+template <class C, bool EXPORT>
 BP_DEV void window_reduce_block(const u32* __restrict__ buckets, size_t nbt, size_t base, u32 nb, int log_nb,
                                 int post_dbl, u32* __restrict__ out) {
   using F = typename C::Fq;
@@ -1509,6 +1523,7 @@ BP_DEV void window_reduce_block(const u32* __restrict__ buckets, size_t nbt, siz
   }
   if (tid == 0) {
     Xyzz v = xyzz_load_aos(term);
+    if constexpr (EXPORT) v = xyzz_export<C>(v);
     xyzz_store_aos(out, v);
   }
 }
@@ -1517,8 +1532,8 @@ template <class C>
 __global__ __launch_bounds__(256) void k_window_reduce_small(const u32* __restrict__ buckets, size_t nbt,
                                                              u32 n_buckets, int log_nb,
                                                              u32* __restrict__ windows) {
-  window_reduce_block<C>(buckets, nbt, (size_t)blockIdx.x * n_buckets, n_buckets, log_nb, 0,
-                         windows + (size_t)blockIdx.x * 32);
+  window_reduce_block<C, true>(buckets, nbt, (size_t)blockIdx.x * n_buckets, n_buckets, log_nb, 0,
+                               windows + (size_t)blockIdx.x * 32);
 }
 
 // ---- 5''. bucket reduction by row and column sums -----------------------------------------
@@ -1593,7 +1608,7 @@ __global__ __launch_bounds__(256) void k_rowcol_final(const u32* __restrict__ co
   const bool is_rows = blockIdx.x >= (u32)n_windows;
   const u32 w = is_rows ? blockIdx.x - (u32)n_windows : blockIdx.x;
   const u32 nb = is_rows ? n_rows : kRowcolCols;
-  window_reduce_block<C>(is_rows ? rows : cols, (size_t)n_windows * nb, (size_t)w * nb, nb, is_rows ? log_rows : 8,
+  window_reduce_block<C, false>(is_rows ? rows : cols, (size_t)n_windows * nb, (size_t)w * nb, nb, is_rows ? log_rows : 8,
                          is_rows ? 8 : 0, parts + (size_t)blockIdx.x * 32);
 }
 
@@ -1645,7 +1660,7 @@ __global__ __launch_bounds__(256) void k_reduce_segments(const u32* __restrict__
 // Block b sums `count` consecutive XYZZ points (AoS) starting at in + b*count:
 // every lane first adds its strided share serially, then a tree over the lanes that
 // hold data (depth = ceil(count/256) - 1 + log2(min(count, 256)) additions).
-template <class C>
+template <class C, bool EXPORT>
 __global__ __launch_bounds__(256) void k_group_sum(const u32* __restrict__ in, u32 count,
                                                    u32* __restrict__ out) {
   using F = typename C::Fq;
@@ -1668,11 +1683,14 @@ __global__ __launch_bounds__(256) void k_group_sum(const u32* __restrict__ in, u
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) xyzz_store_aos(out + (size_t)blockIdx.x * 32, acc);
+  if (threadIdx.x == 0) {
+    if constexpr (EXPORT) acc = xyzz_export<C>(acc);
+    xyzz_store_aos(out + (size_t)blockIdx.x * 32, acc);
+  }
 }
 
 // window-wise sum over parts (multi-GPU combine): out[w] = sum_p in[p][w]
-template <class C>
+template <class C, bool EXPORT>
 __global__ __launch_bounds__(64) void k_window_combine(const u32* __restrict__ in, int n_parts,
                                                        int n_windows, u32* __restrict__ out) {
   using F = typename C::Fq;
@@ -1683,13 +1701,21 @@ __global__ __launch_bounds__(64) void k_window_combine(const u32* __restrict__ i
     Xyzz v = xyzz_load_aos(in + ((size_t)p * n_windows + w) * 32);
     xyzz_add<F>(acc, v);
   }
+  if constexpr (EXPORT) acc = xyzz_export<C>(acc);
   xyzz_store_aos(out + (size_t)w * 32, acc);
 }
 
+// Window sums that have left the pipeline (several GPUs' partial results) are in the boundary
+// form, so this sum runs on the curve types of the boundary.
 hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int n_windows, u32* out,
                                  hipStream_t st) {
-  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_window_combine<C>, dim3((n_windows + 63) / 64), dim3(64),
-                                           0, st, windows, n_parts, n_windows, out));
+  const dim3 grid((n_windows + 63) / 64), block(64);
+  if (curve == BP_SECP256K1)
+    hipLaunchKernelGGL((k_window_combine<Secp256k1, false>), grid, block, 0, st, windows, n_parts, n_windows, out);
+  else if (curve == BP_VESTA)
+    hipLaunchKernelGGL((k_window_combine<Vesta, false>), grid, block, 0, st, windows, n_parts, n_windows, out);
+  else
+    return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
@@ -2025,7 +2051,7 @@ static hipError_t msm_reduce(int curve, const MsmPlan& plan, const MsmWorkspace&
         hipError_t e = launch_rowcol_final_quad(curve, cols, rows, plan.n_windows, n_rows, parts, st);
         if (e != hipSuccess) return e;
       }
-      hipLaunchKernelGGL(k_window_combine<C>, dim3((plan.n_windows + 63) / 64), dim3(64), 0, st, parts, 2,
+      hipLaunchKernelGGL((k_window_combine<C, true>), dim3((plan.n_windows + 63) / 64), dim3(64), 0, st, parts, 2,
                          plan.n_windows, ws.windows);
     });
     return hipGetLastError();
@@ -2041,10 +2067,10 @@ static hipError_t msm_reduce(int curve, const MsmPlan& plan, const MsmWorkspace&
     // window value = sum of its segment values, in one or two tree stages
     if (plan.n_segs > 1024) {
       u32 groups = plan.n_segs / 1024;  // n_segs is a power of two
-      hipLaunchKernelGGL(k_group_sum<C>, dim3(plan.n_windows * groups), dim3(256), 0, st, ws.segs, 1024u, ws.seg_groups);
-      hipLaunchKernelGGL(k_group_sum<C>, dim3(plan.n_windows), dim3(256), 0, st, ws.seg_groups, groups, ws.windows);
+      hipLaunchKernelGGL((k_group_sum<C, false>), dim3(plan.n_windows * groups), dim3(256), 0, st, ws.segs, 1024u, ws.seg_groups);
+      hipLaunchKernelGGL((k_group_sum<C, true>), dim3(plan.n_windows), dim3(256), 0, st, ws.seg_groups, groups, ws.windows);
     } else {
-      hipLaunchKernelGGL(k_group_sum<C>, dim3(plan.n_windows), dim3(256), 0, st, ws.segs, plan.n_segs, ws.windows);
+      hipLaunchKernelGGL((k_group_sum<C, true>), dim3(plan.n_windows), dim3(256), 0, st, ws.segs, plan.n_segs, ws.windows);
     }
   });
   return hipGetLastError();

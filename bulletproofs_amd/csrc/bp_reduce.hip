@@ -23,7 +23,7 @@ namespace bp {
 #define DISPATCH_CURVE_R(curve, STMT) \
   switch (curve) {                    \
     case BP_SECP256K1: {              \
-      using C = Secp256k1;            \
+      using C = Secp256k1P;           \
       STMT;                           \
     } break;                          \
     case BP_VESTA: {                  \
@@ -213,7 +213,8 @@ BP_DEV bool quad_task(u32 task, int t, u32 nb, u32& dst, u32& src) {
 // V = sum_{m=1}^{nb} m * B_{m-1} over buckets base .. base + nb - 1 of an SoA array with plane
 // stride nbt, nb a power of two in 2..256, doubled post_dbl times, to out (XYZZ, 32 words).
 // One block of kQuadThreads lanes; see k_window_reduce_small in bp_msm.hip for the two trees.
-template <class C>
+// EXPORT: the result leaves the pipeline (a window sum): coordinates go back to the boundary form
+template <class C, bool EXPORT>
 BP_DEV void window_reduce_block_quad(const u32* __restrict__ buckets, size_t nbt, size_t base, u32 nb, int log_nb,
                                      int post_dbl, u32* __restrict__ out) {
   using F = typename C::Fq;
@@ -266,15 +267,19 @@ BP_DEV void window_reduce_block_quad(const u32* __restrict__ buckets, size_t nbt
     if (st) fe_store(term + quad * 32 + coord * 8, v);
     __syncthreads();
   }
-  if (quad == 0) fe_store(out + coord * 8, fe_load(term + coord * 8));
+  if (quad == 0) {
+    Fe v = fe_load(term + coord * 8);
+    if constexpr (EXPORT) v = fe_export<C>(v);
+    fe_store(out + coord * 8, v);
+  }
 }
 
 template <class C>
 __global__ __launch_bounds__(kQuadThreads) void k_window_reduce_quad(const u32* __restrict__ buckets, size_t nbt,
                                                                      u32 n_buckets, int log_nb,
                                                                      u32* __restrict__ windows) {
-  window_reduce_block_quad<C>(buckets, nbt, (size_t)blockIdx.x * n_buckets, n_buckets, log_nb, 0,
-                              windows + (size_t)blockIdx.x * 32);
+  window_reduce_block_quad<C, true>(buckets, nbt, (size_t)blockIdx.x * n_buckets, n_buckets, log_nb, 0,
+                                    windows + (size_t)blockIdx.x * 32);
 }
 
 // Blocks 0 .. n_windows-1: parts[w] = sum_q (q+1)*Csum_q over the 256 column sums of window w;
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(kQuadThreads) void k_rowcol_final_quad(const u32* _
   const bool is_rows = blockIdx.x >= (u32)n_windows;
   const u32 w = is_rows ? blockIdx.x - (u32)n_windows : blockIdx.x;
   const u32 nb = is_rows ? n_rows : 256u;
-  window_reduce_block_quad<C>(is_rows ? rows : cols, (size_t)n_windows * nb, (size_t)w * nb, nb,
+  window_reduce_block_quad<C, false>(is_rows ? rows : cols, (size_t)n_windows * nb, (size_t)w * nb, nb,
                               is_rows ? log_rows : 8, is_rows ? 8 : 0, parts + (size_t)blockIdx.x * 32);
 }
 

@@ -304,7 +304,11 @@ int bp_bench_int_mad_peak(bp_ctx* ctx, int iters, double* mac_per_s);
  * Vesta's Fq.  256 (ids 0,1,4) or 128 lanes per block.
  * id 5 = scattered read of every 64-byte record of a 2^iters-record table exactly once
  * (the MSM point-gather pattern with a known byte count, 64 * 2^iters, for calibrating
- * memory counters); `blocks` is ignored, 10 <= iters <= 26. */
+ * memory counters); `blocks` is ignored, 10 <= iters <= 26.
+ * id 6 = as 0 and id 7 = as 2 on the secp256k1 base field in its plain (non-Montgomery) form,
+ * the representation the MSM pipeline uses internally; id 8 = self-check of that multiply against
+ * its portable form over chains of `iters` products: *ms receives the number of lanes that
+ * disagreed (0 = pass). */
 int bp_microbench(bp_ctx* ctx, int id, int blocks, int iters, float* ms);
 /* The event markers behind bp_last_kernel_ms for MSMs (four per MSM, a few microseconds each on the
  * stream) can be turned off for latency-bound callers (the IPA rounds of a proof); on by default.

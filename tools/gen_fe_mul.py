@@ -33,10 +33,13 @@ def limbs(v):
 class Asm:
     """one asm statement: in/out operands acc, ovf plus read-only inputs"""
 
-    def __init__(self):
+    def __init__(self, fresh_ovf=False):
         self.lines = []
         self.inputs = []  # (constraint, expr)
         self.index = {}
+        # fresh_ovf: the first carry count of this statement sets ovf (0 + 0 + carry) instead of
+        # adding to it, so the caller need not clear it
+        self.fresh_ovf = fresh_ovf
 
     def operand(self, constraint, expr):
         key = (constraint, expr)
@@ -45,9 +48,15 @@ class Asm:
             self.inputs.append(key)
         return "%%%d" % self.index[key]
 
-    def mac(self, a_ref, b_ref):
+    def mac(self, a_ref, b_ref, carry=True):
+        """carry=False: the caller knows that the 64-bit accumulator cannot overflow here"""
         self.lines.append("v_mad_u64_u32 %%0, vcc, %s, %s, %%0" % (a_ref, b_ref))
-        self.lines.append("v_addc_co_u32 %1, vcc, 0, %1, vcc")
+        if carry:
+            if self.fresh_ovf:
+                self.lines.append("v_addc_co_u32 %1, vcc, 0, 0, vcc")
+                self.fresh_ovf = False
+            else:
+                self.lines.append("v_addc_co_u32 %1, vcc, 0, %1, vcc")
 
     def emit(self, out, indent="  "):
         if not self.lines:
@@ -127,14 +136,66 @@ def gen_field(name, p):
     return out
 
 
+def gen_secp_plain():
+    """secp256k1 base field on plain residues (no Montgomery factor): p = 2^256 - c with
+    c = 2^32 + 977, so the upper half of a product folds into the lower half by a multiplication
+    with c.  The high columns (8..15) are summed first, without the carry of column 7; their
+    limbs h_k then enter the low columns as 977*h_k + h_(k-1) next to the partial products, and what
+    is left above column 7 (its carry plus h_7) is folded once more.  64 + 8 multiplications and
+    8 additions by a multiply-accumulate with 1, against 88 of the Montgomery form."""
+    name = "Secp256k1FqP"
+    out = []
+    out.append("// %s: residues mod p = 2^256 - 2^32 - 977 as plain integers" % name)
+    out.append("__device__ __forceinline__ Fe fe_mul_dev_%s(const Fe& a, const Fe& b) {" % name)
+    out.append("  uint64_t acc = 0;")
+    out.append("  uint32_t ovf = 0;")
+    out.append("  uint32_t h0, h1, h2, h3, h4, h5, h6, h7;")
+    out.append("  Fe r;")
+    for k in range(8, 15):
+        out.append("  // column %d" % k)
+        ab = Asm(fresh_ovf=True)
+        first = k == 8  # the accumulator starts at zero: one product cannot overflow it
+        for i in range(8):
+            j = k - i
+            if 0 <= j <= 7:
+                ab.mac(ab.operand("v", "a.v[%d]" % i), ab.operand("v", "b.v[%d]" % j), carry=not first)
+                first = False
+        ab.emit(out)
+        out.append("  h%d = (uint32_t)acc;" % (k - 8))
+        out.append("  acc = (acc >> 32) | ((uint64_t)ovf << 32);")
+    out.append("  h7 = (uint32_t)acc;  // column 15: the upper half of a 512-bit product has 256 bits")
+    out.append("  acc = 0;")
+    out.append("  ovf = 0;")
+    for k in range(8):
+        out.append("  // column %d, with 977*h%d%s" % (k, k, " + h%d" % (k - 1) if k else ""))
+        ab = Asm(fresh_ovf=True)
+        # the fold terms first: carry of the last column (< 2^37) + 977 h_k (< 2^42) + h_(k-1)
+        # stays far below 2^64, so these two need no carry count
+        ab.mac(ab.operand("v", "h%d" % k), ab.operand("s", "977u"), carry=False)
+        if k:
+            ab.mac(ab.operand("v", "h%d" % (k - 1)), "1", carry=False)
+        for i in range(8):
+            j = k - i
+            if 0 <= j <= 7:
+                ab.mac(ab.operand("v", "a.v[%d]" % i), ab.operand("v", "b.v[%d]" % j))
+        ab.emit(out)
+        out.append("  r.v[%d] = (uint32_t)acc;" % k)
+        out.append("  acc = (acc >> 32) | ((uint64_t)ovf << 32);")
+    out.append("  return fe_plain_secp_finish(r, acc + h7);")
+    out.append("}")
+    return out
+
+
 def main():
     out = ["// Generated by tools/gen_fe_mul.py -- do not edit.", "#pragma once",
            "// included by bp_field.h inside namespace bp, device compilation only", ""]
     for name, p in FIELDS.items():
         out += gen_field(name, p)
         out.append("")
+    out += gen_secp_plain()
+    out.append("")
     out.append("template <class F>\n__device__ __forceinline__ Fe fe_mul_dev(const Fe& a, const Fe& b);")
-    for name in FIELDS:
+    for name in list(FIELDS) + ["Secp256k1FqP"]:
         out.append("template <>\n__device__ __forceinline__ Fe fe_mul_dev<%s>(const Fe& a, const Fe& b) {\n  return fe_mul_dev_%s(a, b);\n}" % (name, name))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bulletproofs_amd", "csrc", "bp_field_mul_gen.h")
     open(path, "w").write("\n".join(out) + "\n")
