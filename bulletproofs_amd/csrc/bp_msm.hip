@@ -49,6 +49,10 @@ constexpr u32 kChunkKeyInvalid = 63;  // sort key of the unused tail of the chun
 constexpr int kChunkKeyBits = 6;
 // limits of the one-launch front end for small problems (k_small_front)
 constexpr int kSmallThreads = 1024;
+// chunk table (k_ct_*): buckets per lane and per tile of one 1024-lane block, number of sort keys
+constexpr u32 kCtPer = 2;
+constexpr u32 kCtTile = kSmallThreads * kCtPer;
+constexpr u32 kCtKeys = kChunkKeyInvalid + 1;
 constexpr int kSmallIters = 17;
 constexpr size_t kSmallMaxPoints = (size_t)kSmallThreads * kSmallIters;
 constexpr u32 kSmallMaxBuckets = 4096;
@@ -214,16 +218,13 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
                 nbt + 2 >= 2 * (size_t)kTwoLevelMaxBins && !getenv("BP_MSM_RADIX");
   p.nch_bytes = ((nbt + 2 + kMsmMaxStages) * sizeof(u32) + 255) & ~(size_t)255;
   p.chunk_sum_bytes = p.nc_cap * 4 * 32;
-  tmp = 0;
-  e = rocprim::exclusive_scan(nullptr, tmp, (u32*)nullptr, (u32*)nullptr, 0u, nbt + 1, rocprim::plus<u32>(), 0, false);
-  if (e != hipSuccess) return e;
-  p.scan_tmp_bytes = (tmp + 255) & ~(size_t)255;
+  {
+    // chunk table scratch: tile sums, tile offsets, per-tile key histograms, key cursors
+    const size_t n_tiles = (nbt + 1 + kCtTile - 1) / kCtTile;
+    p.scan_tmp_bytes = (((2 + kCtKeys) * n_tiles + kCtKeys) * sizeof(u32) + 255) & ~(size_t)255;
+  }
   p.cdesc_bytes = ((p.nc_cap * sizeof(u32)) + 255) & ~(size_t)255;
-  tmp = 0;
-  e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
-      nullptr, tmp, nullptr, nullptr, nullptr, nullptr, p.nc_cap, 0, kChunkKeyBits, 0, false);
-  if (e != hipSuccess) return e;
-  p.csort_tmp_bytes = (tmp + 255) & ~(size_t)255;
+  p.csort_tmp_bytes = 256;
   *plan = p;
   return hipSuccess;
 }
@@ -1070,50 +1071,203 @@ BP_DEV Xyzz xyzz_export(const Xyzz& p) {
 // bucket boundary, so a bucket of any size (the top window's buckets are denser;
 // degenerate scalar sets put every point in one bucket) costs every lane at most
 // `chunk` additions.  nch[b] = chunks of bucket b; choff = its exclusive scan.
-__global__ __launch_bounds__(256) void k_chunk_counts(const u32* __restrict__ start,
-                                                      const u32* __restrict__ end, size_t nbt, u32 chunk,
-                                                      u32* __restrict__ nch) {
-  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b > nbt) return;
-  nch[b] = b < nbt ? (end[b] - start[b] + chunk - 1) / chunk : 0;
-}
-
 // Chunk descriptors: for chunk t its bucket, first sorted position and a sort key
 // (chunk - length, so that longer chunks come first; kChunkKeyInvalid past the
 // last chunk).  Sorting the chunk ids by that key gives every wave chunks of equal
 // length, which removes the SIMD idle time of uneven chunks.
 
-__global__ __launch_bounds__(256) void k_chunk_desc(const u32* __restrict__ start, const u32* __restrict__ end,
-                                                    const u32* __restrict__ choff, size_t nbt, u32 chunk,
-                                                    size_t nc_cap, u32* __restrict__ ckey,
-                                                    u32* __restrict__ cval, u32* __restrict__ desc_b,
-                                                    u32* __restrict__ desc_s) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nc_cap) return;
-  u32 nc = choff[nbt];
-  cval[t] = (u32)t;
-  if (t >= nc) {
-    ckey[t] = kChunkKeyInvalid;
-    return;
+// ---- chunk table without library calls -------------------------------------------------------
+// The same table as k_chunk_counts + scan + k_chunk_desc + a sort of the chunk ids by length, in
+// four short launches written for this data: the sort key has at most 64 values, so the "sort" is
+// a counting sort whose histogram falls out of the pass that counts the chunks.
+//   k_ct_count    per tile of kCtTile buckets: nch[b], the tile's chunk total and its histogram of keys
+//   k_ct_scan     one block: tile offsets, first slot of every key, total (choff[nbt]), queue reset
+//   k_ct_emit     per bucket: choff[b] = tile offset + scan inside the tile; its chunks' first
+//                 entries and keys; every chunk id goes to the next free slot of its key (rank in
+//                 LDS, one global reservation per key and block)
+// tmp layout (u32): tile_sum[n_tiles] | tile_off[n_tiles] | tile_hist[n_tiles][64] | cursor[64]
+
+__device__ __forceinline__ u32 chunk_key(u32 chunk, u32 len) {  // 0 = full chunk ... kChunkKeyInvalid - 1 = shortest
+  return chunk < kChunkKeyInvalid ? chunk - len : (u32)((size_t)(chunk - len) * (kChunkKeyInvalid - 1) / chunk);
+}
+
+__global__ __launch_bounds__(kSmallThreads) void k_ct_count(const u32* __restrict__ start, const u32* __restrict__ end,
+                                                            size_t nbt, u32 chunk, u32 n_tiles, u32* __restrict__ nch,
+                                                            u32* __restrict__ tmp) {
+  __shared__ u32 hist[kCtKeys];
+  __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
+  if (threadIdx.x < kCtKeys) hist[threadIdx.x] = 0;
+  __syncthreads();
+  u32 mine = 0, full_sum = 0;
+#pragma unroll
+  for (u32 i = 0; i < kCtPer; i++) {
+    const size_t b = (size_t)blockIdx.x * kCtTile + (size_t)i * kSmallThreads + threadIdx.x;
+    if (b > nbt) continue;
+    u32 c = 0;
+    if (b < nbt) {
+      const u32 len = end[b] - start[b];
+      const u32 full = len / chunk, rest = len - full * chunk;
+      c = full + (rest ? 1u : 0u);
+      full_sum += full;
+      if (rest) atomicAdd(&hist[chunk_key(chunk, rest)], 1u);
+    }
+    nch[b] = c;
+    mine += c;
   }
-  size_t lo = 0, hi = nbt;  // last bucket b with choff[b] <= t: choff[lo] <= t < choff[hi]
-  while (hi - lo > 1) {
-    size_t mid = (lo + hi) >> 1;
-    if (choff[mid] <= (u32)t) lo = mid; else hi = mid;
+  // full chunks all share key 0: one LDS addition per wave
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) full_sum += __shfl_down(full_sum, d, 64);
+  if ((threadIdx.x & 63) == 0 && full_sum) atomicAdd(&hist[0], full_sum);
+  u32 total;
+  (void)block_exclusive_scan(mine, wave_sums, &total);
+  if (threadIdx.x == 0) tmp[blockIdx.x] = total;
+  if (threadIdx.x < kCtKeys) tmp[2 * (size_t)n_tiles + (size_t)blockIdx.x * kCtKeys + threadIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kSmallThreads) void k_ct_scan(u32 n_tiles, size_t nbt, u32* __restrict__ tmp,
+                                                           u32* __restrict__ choff, u32* __restrict__ heavy_count) {
+  __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
+  __shared__ u32 keys[kCtKeys];
+  u32 run = 0;
+  for (u32 base = 0; base < n_tiles; base += kSmallThreads) {
+    const u32 t = base + threadIdx.x;
+    const u32 v = t < n_tiles ? tmp[t] : 0;
+    u32 total;
+    const u32 ex = block_exclusive_scan(v, wave_sums, &total);
+    if (t < n_tiles) tmp[n_tiles + t] = run + ex;
+    run += total;
   }
-  u32 k = (u32)t - choff[lo];
-  u32 s = start[lo] + k * chunk, e = end[lo];
-  u32 len = e - s > chunk ? chunk : e - s;
-  desc_b[t] = (u32)lo;
-  desc_s[t] = s;
-  // 0 = full chunk ... kChunkKeyInvalid - 1 = shortest
-  ckey[t] = chunk < kChunkKeyInvalid ? chunk - len : (u32)((size_t)(chunk - len) * (kChunkKeyInvalid - 1) / chunk);
+  if (threadIdx.x == 0) {
+    choff[nbt] = run;  // number of chunks
+    *heavy_count = 0;
+  }
+  // first slot of every key: chunks of key k start after all chunks of smaller keys.  Lane
+  // (key, part) sums every 16th tile's count of its key; the 16 parts are joined in LDS.
+  {
+    __shared__ u32 part_sum[kSmallThreads];
+    const u32 k = threadIdx.x % kCtKeys, part = threadIdx.x / kCtKeys;
+    u32 sum = 0;
+    for (u32 t = part; t < n_tiles; t += kSmallThreads / kCtKeys) sum += tmp[2 * (size_t)n_tiles + (size_t)t * kCtKeys + k];
+    part_sum[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x < kCtKeys) {
+      u32 all = 0;
+      for (u32 q = 0; q < kSmallThreads / kCtKeys; q++) all += part_sum[q * kCtKeys + threadIdx.x];
+      keys[threadIdx.x] = all;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 at = 0;
+    u32* cursor = tmp + 2 * (size_t)n_tiles + (size_t)n_tiles * kCtKeys;
+    for (u32 k = 0; k < kCtKeys; k++) {
+      cursor[k] = at;
+      at += keys[k];
+    }
+  }
+}
+
+// One lane per bucket (kCtPer consecutive buckets): choff[b] from the tile offset and a scan
+// inside the tile, then the bucket's chunk descriptors and their slots in the order sorted by
+// key.  A bucket's full chunks (key 0) take consecutive slots; a bucket with more than
+// kCtSerial chunks is emitted by its whole wave.
+constexpr u32 kCtSerial = 8;
+__global__ __launch_bounds__(kSmallThreads) void k_ct_emit(const u32* __restrict__ start, const u32* __restrict__ end,
+                                                           const u32* __restrict__ nch, size_t nbt, u32 chunk,
+                                                           u32 n_tiles, u32* __restrict__ tmp, u32* __restrict__ choff,
+                                                           u32* __restrict__ ckey, u32* __restrict__ cval,
+                                                           u32* __restrict__ desc_b, u32* __restrict__ desc_s) {
+  __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
+  __shared__ u32 hist[kCtKeys], base[kCtKeys];
+  if (threadIdx.x < kCtKeys) hist[threadIdx.x] = 0;
+  const size_t b0 = (size_t)blockIdx.x * kCtTile + (size_t)threadIdx.x * kCtPer;
+  u32 c[kCtPer], mine = 0;
+#pragma unroll
+  for (u32 i = 0; i < kCtPer; i++) {
+    c[i] = b0 + i < nbt ? nch[b0 + i] : 0;
+    mine += c[i];
+  }
+  u32 total;
+  u32 at = tmp[n_tiles + blockIdx.x] + block_exclusive_scan(mine, wave_sums, &total);  // syncs: hist is clear
+  u32 first[kCtPer], s0[kCtPer], full[kCtPer], rest[kCtPer], rank0[kCtPer], rank1[kCtPer];
+  u32 full_mine = 0;
+#pragma unroll
+  for (u32 i = 0; i < kCtPer; i++) {
+    first[i] = at;
+    at += c[i];
+    s0[i] = full[i] = rest[i] = rank1[i] = 0;
+    if (b0 + i < nbt) {
+      choff[b0 + i] = first[i];
+      s0[i] = start[b0 + i];
+      const u32 len = end[b0 + i] - s0[i];
+      full[i] = len / chunk;
+      rest[i] = len - full[i] * chunk;
+      if (rest[i]) rank1[i] = atomicAdd(&hist[chunk_key(chunk, rest[i])], 1u);
+    }
+    rank0[i] = full_mine;
+    full_mine += full[i];
+  }
+  // slots of the full chunks (key 0): a prefix sum over the wave, one LDS addition per wave
+  {
+    const int lane = threadIdx.x & 63;
+    u32 inc = full_mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const u32 o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    u32 wave_first = 0;
+    if (lane == 63 && inc) wave_first = atomicAdd(&hist[0], inc);
+    wave_first = __shfl(wave_first, 63, 64);
+#pragma unroll
+    for (u32 i = 0; i < kCtPer; i++) rank0[i] += wave_first + inc - full_mine;
+  }
+  __syncthreads();
+  if (threadIdx.x < kCtKeys && hist[threadIdx.x]) {
+    u32* cursor = tmp + 2 * (size_t)n_tiles + (size_t)n_tiles * kCtKeys;
+    base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], hist[threadIdx.x]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 i = 0; i < kCtPer; i++) {
+    const u32 bkt = (u32)(b0 + i);
+    if (rest[i]) {
+      const u32 key = chunk_key(chunk, rest[i]), t = first[i] + full[i], pos = base[key] + rank1[i];
+      desc_b[t] = bkt;
+      desc_s[t] = s0[i] + full[i] * chunk;
+      ckey[pos] = key;
+      cval[pos] = t;
+    }
+    const u32 slot0 = full[i] ? base[0] + rank0[i] : 0;
+    if (full[i] <= kCtSerial) {
+      for (u32 j = 0; j < full[i]; j++) {
+        desc_b[first[i] + j] = bkt;
+        desc_s[first[i] + j] = s0[i] + j * chunk;
+        ckey[slot0 + j] = 0;
+        cval[slot0 + j] = first[i] + j;
+      }
+    }
+    // crowded buckets: the wave writes them together, one after the other
+    unsigned long long big = __ballot(full[i] > kCtSerial);
+    while (big) {
+      const int src = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const u32 n_full = __shfl(full[i], src, 64), f0 = __shfl(first[i], src, 64), st0 = __shfl(s0[i], src, 64);
+      const u32 sl0 = __shfl(slot0, src, 64), bk = __shfl(bkt, src, 64);
+      for (u32 j = threadIdx.x & 63; j < n_full; j += 64) {
+        desc_b[f0 + j] = bk;
+        desc_s[f0 + j] = st0 + j * chunk;
+        ckey[sl0 + j] = 0;
+        cval[sl0 + j] = f0 + j;
+      }
+    }
+  }
 }
 
 template <class C>
 __global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ packed,
                                                     const u32* __restrict__ vals,
-                                                    const u32* __restrict__ ckey,
+                                                    const u32* __restrict__ choff_total,
                                                     const u32* __restrict__ cval,
                                                     const u32* __restrict__ desc_b,
                                                     const u32* __restrict__ desc_s,
@@ -1123,9 +1277,7 @@ __global__ __launch_bounds__(128) void k_chunk_sums(const u32* __restrict__ pack
                                                     u32* __restrict__ chunk_sums) {
   using F = typename C::Fq;
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= nc_cap) return;
-  u32 key = ckey[j];
-  if (key == kChunkKeyInvalid) return;
+  if (j >= nc_cap || j >= choff_total[0]) return;  // slots past the last chunk are unused
   u32 t = cval[j];
   u32 b = desc_b[t];
   u32 s = desc_s[t], e = s + chunk;
@@ -1906,21 +2058,14 @@ static hipError_t msm_sort_and_chunk(const MsmPlan& plan, const MsmWorkspace& ws
 // chunk table of sorted entries with known bucket bounds, sorted by chunk length
 static hipError_t msm_chunk_table(const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st) {
   const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
-  hipError_t e;
-  size_t tmp;
-  hipLaunchKernelGGL(k_chunk_counts, dim3((unsigned)((nbt + 256) / 256)), dim3(256), 0, st, ws.bucket_start,
-                     ws.bucket_end, nbt, plan.chunk, ws.nch);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  tmp = plan.scan_tmp_bytes;
-  e = rocprim::exclusive_scan(ws.scan_tmp, tmp, ws.nch, ws.choff, 0u, nbt + 1, rocprim::plus<u32>(), st, false);
-  if (e != hipSuccess) return e;
-  if ((e = hipMemsetAsync(ws.heavy_count, 0, sizeof(u32), st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_chunk_desc, dim3((unsigned)((plan.nc_cap + 255) / 256)), dim3(256), 0, st, ws.bucket_start,
-                     ws.bucket_end, ws.choff, nbt, plan.chunk, plan.nc_cap, ws.ckey_a, ws.cval_a, ws.desc_b, ws.desc_s);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  tmp = plan.csort_tmp_bytes;
-  return rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
-      ws.csort_tmp, tmp, ws.ckey_a, ws.ckey_b, ws.cval_a, ws.cval_b, plan.nc_cap, 0, kChunkKeyBits, st, false);
+  const u32 n_tiles = (u32)((nbt + 1 + kCtTile - 1) / kCtTile);
+  u32* tmp = (u32*)ws.scan_tmp;
+  hipLaunchKernelGGL(k_ct_count, dim3(n_tiles), dim3(kSmallThreads), 0, st, ws.bucket_start, ws.bucket_end, nbt,
+                     plan.chunk, n_tiles, ws.nch, tmp);
+  hipLaunchKernelGGL(k_ct_scan, dim3(1), dim3(kSmallThreads), 0, st, n_tiles, nbt, tmp, ws.choff, ws.heavy_count);
+  hipLaunchKernelGGL(k_ct_emit, dim3(n_tiles), dim3(kSmallThreads), 0, st, ws.bucket_start, ws.bucket_end, ws.nch, nbt,
+                     plan.chunk, n_tiles, tmp, ws.choff, ws.ckey_b, ws.cval_b, ws.desc_b, ws.desc_s);
+  return hipGetLastError();
 }
 
 // accumulation and reduction over a finished entry order and chunk table
@@ -1983,7 +2128,7 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
     if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;
   } else {
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_chunk_sums<C>, dim3((unsigned)((plan.nc_cap + 127) / 128)), dim3(128),
-                                             0, st, ws.packed, ws.vals_b, ws.ckey_b, ws.cval_b, ws.desc_b, ws.desc_s,
+                                             0, st, ws.packed, ws.vals_b, ws.choff + nbt, ws.cval_b, ws.desc_b, ws.desc_s,
                                              ws.bucket_end, ws.nch, nbt, plan.chunk, plan.nc_cap, idx_mask, ws.buckets,
                                              ws.chunk_sums));
     if ((e = hipGetLastError()) != hipSuccess) return e;
