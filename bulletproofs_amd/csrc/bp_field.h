@@ -254,12 +254,17 @@ BP_DEV Fe fe_sqr(const Fe& a) {
   return fe_mul<F>(a, a);
 }
 
-// Montgomery form -> canonical integer (multiply by 1)
+// Montgomery form -> canonical integer: the reduction alone on the device (a multiplication by 1
+// whose partial products are never issued), a multiplication by 1 elsewhere
 template <class F>
 BP_DEV Fe fe_from_mont(const Fe& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return fe_redc_dev<F>(a);
+#else
   Fe one = fe_zero();
   one.v[0] = 1;
   return fe_mul<F>(a, one);
+#endif
 }
 
 template <class F>

@@ -204,8 +204,8 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
 // window values of 2..256 buckets per window, four lanes per point addition (bp_reduce.hip)
 hipError_t launch_window_reduce_quad(int curve, const u32* buckets, size_t nbt, u32 n_buckets, int n_windows,
                                      u32* windows, hipStream_t st);
-hipError_t launch_rowcol_final_quad(int curve, const u32* cols, const u32* rows, int n_windows, u32 n_rows,
-                                    u32* parts, hipStream_t st);
+hipError_t launch_rowcol_final_quad(int curve, const u32* cols, const u32* rows, int n_windows, u32 n_rows, u32* parts,
+                                    u32* done, u32* windows, hipStream_t st);
 hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int n_windows, u32* out,
                                  hipStream_t st);
 

@@ -46,7 +46,6 @@ namespace bp {
   }
 
 constexpr u32 kChunkKeyInvalid = 63;  // sort key of the unused tail of the chunk table
-constexpr int kChunkKeyBits = 6;
 // limits of the one-launch front end for small problems (k_small_front)
 constexpr int kSmallThreads = 1024;
 // chunk table (k_ct_*): buckets per lane and per tile of one 1024-lane block, number of sort keys
@@ -422,6 +421,20 @@ __global__ __launch_bounds__(1024) void k_small_front(
   u32 my_key[kSmallIters], my_val[kSmallIters], my_rank[kSmallIters];
   const u32 invalid = n_buckets;
   const int bit0 = (int)(w * (u32)c), limb = bit0 >> 5, sh = bit0 & 31;
+  // Packing: every point's x|y record is written (in the pipeline's form) by exactly one lane of
+  // the grid, ahead of the digit loop so that the conversion does not share registers with it.
+#pragma unroll 1
+  for (size_t i = (size_t)threadIdx.x * gridDim.x + wid; i < n; i += (size_t)kSmallThreads * gridDim.x) {
+    const bool second = i >= n0;
+    const u32* px = second ? x1 + (i - n0) * 8 : x0 + i * 8;
+    const u32* py = second ? y1 + (i - n0) * 8 : y0 + i * 8;
+    if (i >= n01) {
+      px = sel.extra_xy[i - n01];
+      py = px + 8;
+    }
+    fe_store(packed + i * 16, fe_import<C>(fe_load(px)));
+    fe_store(packed + i * 16 + 8, fe_import<C>(fe_load(py)));
+  }
 #pragma unroll
   for (int it = 0; it < kSmallIters; it++) {
     my_key[it] = invalid;
@@ -444,18 +457,6 @@ __global__ __launch_bounds__(1024) void k_small_front(
       }
     }
     if (grp != g) continue;
-    // every point is packed (and brought into the pipeline's form) by one block of its group:
-    // spread over the group's window blocks, so that no block has more than its share to convert
-    if ((u32)(i % (size_t)group_windows) == w) {
-      const u32* px = second ? x1 + (i - n0) * 8 : x0 + i * 8;
-      const u32* py = second ? y1 + (i - n0) * 8 : y0 + i * 8;
-      if (is_extra) {
-        px = sel.extra_xy[i - n01];
-        py = px + 8;
-      }
-      fe_store(packed + i * 16, fe_import<C>(fe_load(px)));
-      fe_store(packed + i * 16 + 8, fe_import<C>(fe_load(py)));
-    }
     const u32* sp = second ? s1 + (i - n0) * 8 : s0 + i * 8;
     if (is_extra) sp = sel.extra_s[i - n01];
     const bool is_inf = is_extra ? false : (second ? (inf1 && inf1[i - n0]) : (inf0 && inf0[i]));
@@ -1137,10 +1138,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_ct_scan(u32 n_tiles, size_t n
     if (t < n_tiles) tmp[n_tiles + t] = run + ex;
     run += total;
   }
-  if (threadIdx.x == 0) {
-    choff[nbt] = run;  // number of chunks
-    *heavy_count = 0;
-  }
+  if (threadIdx.x == 0) choff[nbt] = run;  // number of chunks
+  // the queue counter and, behind it, the per-window arrival counters of the row/column reduction
+  if (threadIdx.x < 64) heavy_count[threadIdx.x] = 0;
   // first slot of every key: chunks of key k start after all chunks of smaller keys.  Lane
   // (key, part) sums every 16th tile's count of its key; the 16 parts are joined in LDS.
   {
@@ -1703,9 +1703,12 @@ __global__ __launch_bounds__(256) void k_window_reduce_small(const u32* __restri
 template <class C>
 __global__ __launch_bounds__(256) void k_rowcol_sums(const u32* __restrict__ buckets, size_t nbt, u32 n_buckets,
                                                      int n_windows, u32 row_blocks, int row_lanes, int col_lanes,
-                                                     u32* __restrict__ cols, u32* __restrict__ rows) {
+                                                     u32* __restrict__ cols, u32* __restrict__ rows,
+                                                     u32* __restrict__ done) {
   using F = typename C::Fq;
   const u32 n_rows = n_buckets / kRowcolCols;
+  // arrival counters of the launch that follows (k_rowcol_final_quad joins a window's two parts)
+  if (done != nullptr && blockIdx.x == 0 && (int)threadIdx.x < n_windows) done[threadIdx.x] = 0;
   Xyzz acc = xyzz_identity<F>();
   if (blockIdx.x < row_blocks) {
     const u32 kLanes = (u32)row_lanes;
@@ -2188,16 +2191,21 @@ static hipError_t msm_reduce(int curve, const MsmPlan& plan, const MsmWorkspace&
     u32* parts = rows + nw * n_rows * 32;
     DISPATCH_CURVE(curve, {
       hipLaunchKernelGGL(k_rowcol_sums<C>, dim3(row_blocks + col_blocks), dim3(256), 0, st, ws.buckets, nbt,
-                         plan.n_buckets, plan.n_windows, row_blocks, row_lanes, col_lanes, cols, rows);
+                         plan.n_buckets, plan.n_windows, row_blocks, row_lanes, col_lanes, cols, rows,
+                         serial_reduce ? nullptr : ws.heavy_count + 1);
       if (serial_reduce) {
         hipLaunchKernelGGL(k_rowcol_final<C>, dim3(2 * (unsigned)plan.n_windows), dim3(256), 0, st, cols, rows,
                            plan.n_windows, n_rows, log_rows, parts);
+        hipLaunchKernelGGL((k_window_combine<C, true>), dim3((plan.n_windows + 63) / 64), dim3(64), 0, st, parts, 2,
+                           plan.n_windows, ws.windows);
       } else {
-        hipError_t e = launch_rowcol_final_quad(curve, cols, rows, plan.n_windows, n_rows, parts, st);
+        // the second of a window's two blocks to finish adds the parts (counters behind heavy_count,
+        // cleared by k_rowcol_sums)
+        if (plan.n_windows > 63) return hipErrorInvalidValue;
+        hipError_t e = launch_rowcol_final_quad(curve, cols, rows, plan.n_windows, n_rows, parts, ws.heavy_count + 1,
+                                                ws.windows, st);
         if (e != hipSuccess) return e;
       }
-      hipLaunchKernelGGL((k_window_combine<C, true>), dim3((plan.n_windows + 63) / 64), dim3(64), 0, st, parts, 2,
-                         plan.n_windows, ws.windows);
     });
     return hipGetLastError();
   }

@@ -214,9 +214,14 @@ BP_DEV bool quad_task(u32 task, int t, u32 nb, u32& dst, u32& src) {
 // stride nbt, nb a power of two in 2..256, doubled post_dbl times, to out (XYZZ, 32 words).
 // One block of kQuadThreads lanes; see k_window_reduce_small in bp_msm.hip for the two trees.
 // EXPORT: the result leaves the pipeline (a window sum): coordinates go back to the boundary form
-template <class C, bool EXPORT>
+// JOIN: the block's result is one of the two parts of window join_w (parts[join_w] and
+// parts[n_windows + join_w]); the block that finishes second (counted in done[join_w], zero before
+// the launch) adds the two and writes the window sum to windows[join_w], in the boundary form.
+template <class C, bool EXPORT, bool JOIN = false>
 BP_DEV void window_reduce_block_quad(const u32* __restrict__ buckets, size_t nbt, size_t base, u32 nb, int log_nb,
-                                     int post_dbl, u32* __restrict__ out) {
+                                     int post_dbl, u32* __restrict__ out, u32* __restrict__ done = nullptr,
+                                     const u32* __restrict__ parts = nullptr, u32 n_windows = 0, u32 join_w = 0,
+                                     u32* __restrict__ windows = nullptr) {
   using F = typename C::Fq;
   __shared__ u32 slot[kQuadMaxBuckets * 32];
   __shared__ u32 term[16 * 32];
@@ -272,6 +277,29 @@ BP_DEV void window_reduce_block_quad(const u32* __restrict__ buckets, size_t nbt
     if constexpr (EXPORT) v = fe_export<C>(v);
     fe_store(out + coord * 8, v);
   }
+  if constexpr (JOIN) {
+    __shared__ u32 arrival;
+    __threadfence();  // the part is visible before the count says so
+    __syncthreads();
+    if (tid == 0) arrival = atomicAdd(&done[join_w], 1u);
+    __syncthreads();
+    if (arrival == 1 && quad == 0) {
+      __threadfence();  // acquire: the other block's part (another XCD's L2 may hold it) after its count
+      // both parts are in memory; read past this CU's cache (the other part was written by another block)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const u32* src = parts + ((size_t)h * n_windows + join_w) * 32 + coord * 8;
+        Fe v;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v.v[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fe_store(term + h * 32 + coord * 8, v);
+      }
+      quad_sync();
+      Fe v;
+      if (!quad_add<F>(term, scr, zero, 0, 1, role, v)) v = fe_load(term + coord * 8);
+      fe_store(windows + (size_t)join_w * 32 + coord * 8, fe_export<C>(v));
+    }
+  }
 }
 
 template <class C>
@@ -289,12 +317,14 @@ template <class C>
 __global__ __launch_bounds__(kQuadThreads) void k_rowcol_final_quad(const u32* __restrict__ cols,
                                                                     const u32* __restrict__ rows, int n_windows,
                                                                     u32 n_rows, int log_rows,
-                                                                    u32* __restrict__ parts) {
+                                                                    u32* __restrict__ parts, u32* __restrict__ done,
+                                                                    u32* __restrict__ windows) {
   const bool is_rows = blockIdx.x >= (u32)n_windows;
   const u32 w = is_rows ? blockIdx.x - (u32)n_windows : blockIdx.x;
   const u32 nb = is_rows ? n_rows : 256u;
-  window_reduce_block_quad<C, false>(is_rows ? rows : cols, (size_t)n_windows * nb, (size_t)w * nb, nb,
-                              is_rows ? log_rows : 8, is_rows ? 8 : 0, parts + (size_t)blockIdx.x * 32);
+  window_reduce_block_quad<C, false, true>(is_rows ? rows : cols, (size_t)n_windows * nb, (size_t)w * nb, nb,
+                                           is_rows ? log_rows : 8, is_rows ? 8 : 0, parts + (size_t)blockIdx.x * 32, done,
+                                           parts, (u32)n_windows, w, windows);
 }
 
 hipError_t launch_window_reduce_quad(int curve, const u32* buckets, size_t nbt, u32 n_buckets, int n_windows,
@@ -307,13 +337,15 @@ hipError_t launch_window_reduce_quad(int curve, const u32* buckets, size_t nbt, 
   return hipGetLastError();
 }
 
+// done: n_windows counters that are zero (the chunk table's scan clears them); the window sums go
+// to `windows` in the boundary form
 hipError_t launch_rowcol_final_quad(int curve, const u32* cols, const u32* rows, int n_windows, u32 n_rows,
-                                    u32* parts, hipStream_t st) {
+                                    u32* parts, u32* done, u32* windows, hipStream_t st) {
   if (n_rows < 2 || n_rows > kQuadMaxBuckets || (n_rows & (n_rows - 1))) return hipErrorInvalidValue;
   int log_rows = 0;
   while ((1u << log_rows) < n_rows) log_rows++;
   DISPATCH_CURVE_R(curve, hipLaunchKernelGGL(k_rowcol_final_quad<C>, dim3(2 * (unsigned)n_windows), dim3(kQuadThreads),
-                                             0, st, cols, rows, n_windows, n_rows, log_rows, parts));
+                                             0, st, cols, rows, n_windows, n_rows, log_rows, parts, done, windows));
   return hipGetLastError();
 }
 

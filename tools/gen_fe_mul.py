@@ -84,14 +84,19 @@ def ones_run_start(pl):
     return s if 8 - s >= 3 and s >= 1 else 8
 
 
-def gen_field(name, p):
+def gen_field(name, p, redc=False):
+    """redc=True: the Montgomery reduction alone, a * 2^-256 mod p (the multiply with b = 1: a's
+    limbs enter their columns directly, the 64 partial products are not issued)"""
     pl = limbs(p)
     inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
     run = ones_run_start(pl)
     signed = run < 8
     out = []
     out.append("// %s: p = 0x%064x" % (name, p))
-    out.append("__device__ __forceinline__ Fe fe_mul_dev_%s(const Fe& a, const Fe& b) {" % name)
+    if redc:
+        out.append("__device__ __forceinline__ Fe fe_redc_dev_%s(const Fe& a) {" % name)
+    else:
+        out.append("__device__ __forceinline__ Fe fe_mul_dev_%s(const Fe& a, const Fe& b) {" % name)
     out.append("  uint64_t acc = 0;")
     out.append("  uint32_t ovf = 0;")
     out.append("  uint32_t m0, m1, m2, m3, m4, m5, m6, m7;")
@@ -99,10 +104,16 @@ def gen_field(name, p):
     for k in range(15):
         out.append("  // column %d" % k)
         ab = Asm()
-        for i in range(8):
-            j = k - i
-            if 0 <= j <= 7:
-                ab.mac(ab.operand("v", "a.v[%d]" % i), ab.operand("v", "b.v[%d]" % j))
+        if redc:
+            if k < 8:
+                # unsigned accumulator: carry of the last column (a few bits above 2^32) + a_k cannot
+                # overflow; a signed one (telescoped modulus) may be negative, and its carry counts
+                ab.mac(ab.operand("v", "a.v[%d]" % k), "1", carry=signed)
+        else:
+            for i in range(8):
+                j = k - i
+                if 0 <= j <= 7:
+                    ab.mac(ab.operand("v", "a.v[%d]" % i), ab.operand("v", "b.v[%d]" % j))
         ab.emit(out)
         mp = Asm()
         for i in range(8):
@@ -192,11 +203,16 @@ def main():
     for name, p in FIELDS.items():
         out += gen_field(name, p)
         out.append("")
+        out += gen_field(name, p, redc=True)
+        out.append("")
     out += gen_secp_plain()
     out.append("")
     out.append("template <class F>\n__device__ __forceinline__ Fe fe_mul_dev(const Fe& a, const Fe& b);")
     for name in list(FIELDS) + ["Secp256k1FqP"]:
         out.append("template <>\n__device__ __forceinline__ Fe fe_mul_dev<%s>(const Fe& a, const Fe& b) {\n  return fe_mul_dev_%s(a, b);\n}" % (name, name))
+    out.append("template <class F>\n__device__ __forceinline__ Fe fe_redc_dev(const Fe& a);")
+    for name in FIELDS:
+        out.append("template <>\n__device__ __forceinline__ Fe fe_redc_dev<%s>(const Fe& a) {\n  return fe_redc_dev_%s(a);\n}" % (name, name))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bulletproofs_amd", "csrc", "bp_field_mul_gen.h")
     open(path, "w").write("\n".join(out) + "\n")
     print("wrote", os.path.normpath(path))
