@@ -31,13 +31,23 @@ sys.path.insert(0, ROOT)
 LOG2_N = 20
 SEED = 0xB0117E7 + 2  # config index 2 of BASELINE.json ("Standalone MSM 2^16..2^20")
 MADD_MULS = 10        # XYZZ mixed addition: 8M + 2S
-MAC_PER_MUL = 136     # 8-limb Montgomery multiply: 2*8*8 + 8 32x32 multiply-accumulates
+MAC_PER_MUL = 136     # 8-limb Montgomery multiply: 2*8*8 + 8 32x32 multiply-accumulates (algorithmic credit)
+# v_mad_u64_u32 the generated device multiply really issues per field product (tools/gen_fe_mul.py):
+# secp256k1's pipeline works on plain residues mod 2^256 - 2^32 - 977 (64 partial products, 8 folds by 977
+# and 9 additions of a 32-bit limb done as multiply-accumulates with 1)
+MAD_ISSUED_PER_MUL = 81
+# whole-MSM arithmetic the bucket method needs per point at n = 2^20, c = 16: 16 windows x one mixed addition
+# priced at 11 M, plus the bucket reduction 2 * 2^15 * 16 full additions of 16 M amortised over n, 136 MAC per M
+WHOLE_STEP_MULS = lambda n, nw, cb: nw * 11 + 2 * (1 << (cb - 1)) * nw * 16 / n  # noqa: E731
+PEAK_PROBES = 6
+PEAK_PROBE_ITERS = 12000  # one probe launch runs >= 50 ms
 # Memory-side bytes of one k_chunk_sums launch at the default size, from separate
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script (averages over the
 # launches; profiles/r01_bench_msm20_v7_pmc_summary.csv).  The counters read KiB; a
 # scattered read of 64-byte records with a known byte count (tools/calib_gather.py,
 # profiles/r01_gather64_calibration.csv) reads back exactly, so no factor is applied.
 PMC_TRAFFIC_2_20 = {"fetch_bytes": 1746220.7 * 1024, "write_bytes": 95412.7 * 1024}
+CPU_MSM_SAMPLES = 5
 
 
 def make_inputs(n, rank):
@@ -100,18 +110,52 @@ def cpu_baseline(n_sample):
     lim = lambda v: np.array([(v >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)  # noqa: E731
     gxy = np.concatenate([lim(gx * r % p), lim(gy * r % p)])
     px, py = co.gen_points(0, gxy, gxy, n_sample)
-    t0 = time.perf_counter()
-    co.msm(0, (px, py, None), ks, cores)
-    dt = time.perf_counter() - t0
+    co.msm(0, (px, py, None), ks, cores)  # untimed: pages in, spins the OpenMP team up
+    times = []
+    for _ in range(CPU_MSM_SAMPLES):
+        t0 = time.perf_counter()
+        co.msm(0, (px, py, None), ks, cores)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     return dict(value=n_sample / dt, unit="points/s", cores=cores, kind="port",
-                sample=f"one 2^{n_sample.bit_length() - 1}-point secp256k1 MSM, C restatement of the bucket method "
-                       f"(oracle/bp_oracle.c, OpenMP over windows), {dt:.2f} s; not the arkworks binary")
+                sample=f"median of {CPU_MSM_SAMPLES} runs of one 2^{n_sample.bit_length() - 1}-point secp256k1 MSM "
+                       f"(min {min(times):.3f} s, median {dt:.3f} s, max {max(times):.3f} s), C restatement of the bucket "
+                       f"method (oracle/bp_oracle.c, OpenMP over windows); not the arkworks binary")
 
 
-def range_proofs(ctx, device, workers=8, per_worker=8):
+def cpu_range_baseline(gs, hs, ugh, values, gamma, n_bits, seed, samples):
+    """C oracle's range prover and verifier (oracle/bp_oracle_proto.c) on the host cores: the CPU
+    figure beside the range-proof half of the metric.  A C restatement, not the arkworks binary."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+
+    co = c_oracle.COracle()
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    cores = max(1, min(cores, co.max_threads()))
+    tp, tv = [], []
+    for _ in range(samples):
+        t0 = time.perf_counter()
+        pr = co.range_agg_prove(0, gs, hs, ugh, values, gamma, n_bits, seed, seed + 1, threads=cores)
+        t1 = time.perf_counter()
+        res = co.range_agg_verify(0, gs, hs, ugh, values, gamma, n_bits, pr["points"], pr["scalars"], pr["lr"],
+                                  seed ^ 0x5EED, seed + 1, threads=cores)
+        t2 = time.perf_counter()
+        if int(res[8:].any()) != 0:
+            raise SystemExit("C oracle rejected its own range proof")
+        tp.append(t1 - t0)
+        tv.append(t2 - t1)
+    mp, mv = float(np.median(tp)), float(np.median(tv))
+    return dict(prove_per_s=1.0 / mp, verify_per_s=1.0 / mv, prove_ms=mp * 1e3, verify_ms=mv * 1e3, cores=cores, kind="port",
+                sample=f"median of {samples} prove + verify runs, C restatement of src/range/aggregate.rs "
+                       f"(oracle/bp_oracle_proto.c, OpenMP inside the MSMs and folds); not the arkworks binary")
+
+
+def range_proofs(ctx, device, workers=8, per_worker=8, cpu=True):
     """second half of the metric: aggregated range proof, 64 values x 64 bits
     (benches/aggregate_range_bench.rs:93-97), proved and verified through the GPU path by the
-    host mirror with the seeded transcript stand-in; measured outside the timed MSM steps"""
+    host mirror with the seeded transcript stand-in; measured outside the timed MSM steps.  Beside
+    it the single-value 64-bit proof of benches/range_bench.rs:37-62 (the reference's own
+    CPU-runnable case) and, for both, the C oracle timed on the host cores."""
     import bulletproofs_amd as bp
     from bulletproofs_amd import host_mirror
 
@@ -123,7 +167,14 @@ def range_proofs(ctx, device, workers=8, per_worker=8):
                                                  per_worker, seed, seed + 1)
     if not (one["ok"] and thr["ok"]):
         raise SystemExit("aggregated range proof failed to verify")
-    return {
+    g1, h1 = tuple(None if v is None else v[:64] for v in gs), tuple(None if v is None else v[:64] for v in hs)
+    host_mirror.range_aggregate_roundtrip(ctx, bp.SECP256K1, g1, h1, ugh, values[:1], gamma[:1], 64, seed, seed + 1, reps=1,
+                                          single=True)
+    single = host_mirror.range_aggregate_roundtrip(ctx, bp.SECP256K1, g1, h1, ugh, values[:1], gamma[:1], 64, seed, seed + 1,
+                                                   reps=5, single=True)
+    if not single["ok"]:
+        raise SystemExit("single-value range proof failed to verify")
+    out = {
         "metric": "aggregated 64-bit range proofs/sec",
         "workload": "m = 64 values x 64 bits (N = 4096), secp256k1, prove and verify, 1 GPU",
         "prove_per_s": thr["prove_per_s"],
@@ -132,7 +183,13 @@ def range_proofs(ctx, device, workers=8, per_worker=8):
         "one_at_a_time": {"prove_ms": one["prove_ms"], "verify_ms": one["verify_ms"]},
         "note": "host threads with one context each on the same GPU; every proof verified; transcript is a seeded "
                 "stand-in for the reference's Fiat-Shamir sponge",
+        "single_value_64_bit": {"workload": "one 64-bit value (benches/range_bench.rs:37-62 shape), one at a time, 1 GPU",
+                                "prove_ms": single["prove_ms"], "verify_ms": single["verify_ms"]},
     }
+    if cpu:
+        out["cpu_baseline"] = cpu_range_baseline(gs, hs, ugh, values, gamma, 64, seed, 3)
+        out["single_value_64_bit"]["cpu_baseline"] = cpu_range_baseline(g1, h1, ugh, values[:1], gamma[:1], 64, seed, 5)
+    return out
 
 
 def msm_in_flight(bp, device, dx, dy, dk, n, steps, workers=2):
@@ -176,6 +233,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-range", action="store_true", help="skip the aggregated range proof figures")
     ap.add_argument("--no-in-flight", action="store_true", help="skip the two-MSMs-in-flight figure")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 2^log2n points on every GPU; strong: 2^log2n points in total, split by shard_range")
     args = ap.parse_args()
 
     import torch
@@ -197,15 +256,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    n = 1 << args.log2n
+    from bulletproofs_amd.sharded import ShardedMsm, shard_range
+
+    n_total = (1 << args.log2n) * (world if args.scaling == "weak" else 1)
+    begin, end = shard_range(n_total, rank, world)
+    n = end - begin
     ctx = bp.Context(local_rank)
     px, py = gen_points_on_gpu(ctx, n, rank)
     ks = make_inputs(n, rank)
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()  # noqa: E731
     dx, dy, dk = to_dev(px), to_dev(py), to_dev(ks)
-    from bulletproofs_amd.sharded import ShardedMsm
-
-    sharded = ShardedMsm(ctx, bp.SECP256K1, dist=dist if use_dist else None)
+    sharded = ShardedMsm(ctx, bp.SECP256K1, dist=dist if use_dist else None, n_total=n_total)
     win = sharded.win
 
     def step():
@@ -237,27 +298,39 @@ def main():
 
     if rank == 0:
         # plan facts: window width and count chosen by the library for this n
-        nw, cb = ctx.msm_windows_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n, win.data_ptr())
-        peak = ctx.int_mad_peak(4000)
+        if use_dist:
+            cb = sharded.window_bits()
+            nw = ctx.msm_shard_windows_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n, cb, win.data_ptr())
+        else:
+            nw, cb = ctx.msm_windows_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n, win.data_ptr())
+        ctx.int_mad_peak(PEAK_PROBE_ITERS)  # warm-up: clocks up
+        probes = [ctx.int_mad_peak(PEAK_PROBE_ITERS) for _ in range(PEAK_PROBES)]
+        peak = max(probes)
         acc_avg_s = float(np.mean(acc_ms)) * 1e-3
-        macs_per_launch = float(n) * nw * MADD_MULS * MAC_PER_MUL
-        achieved = macs_per_launch / acc_avg_s
+        muls_per_launch = float(n) * nw * MADD_MULS
+        achieved = muls_per_launch * MAC_PER_MUL / acc_avg_s
+        issued = muls_per_launch * MAD_ISSUED_PER_MUL / acc_avg_s
+        step_s = elapsed / args.steps
+        whole_mac_per_point = WHOLE_STEP_MULS(n, nw, cb) * MAC_PER_MUL
         out = {
             "metric": "MSM points/sec at 2^20",
-            "value": world * n * args.steps / elapsed,
+            "value": n_total * args.steps / elapsed,
             "unit": "points/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": step_s * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "u32 limbs (256-bit Montgomery integers)",
+            "dtype": "u32 limbs (256-bit integers mod p)",
             "data": "synthetic",
             "config": {
-                "workload": f"standalone secp256k1 MSM, 2^{args.log2n} points/GPU, uniform scalars, inputs resident in HBM",
+                "workload": (f"standalone secp256k1 MSM, 2^{args.log2n} points/GPU" if args.scaling == "weak" else
+                             f"standalone secp256k1 MSM, 2^{args.log2n} points in total") +
+                            ", uniform scalars, inputs resident in HBM",
                 "points_per_gpu": n,
+                "points_total": n_total,
                 "curve": "secp256k1",
                 "window_bits": cb,
                 "windows": nw,
@@ -272,9 +345,19 @@ def main():
                 "peak": peak / 1e12,
                 "unit": "TMAC/s",
                 "frac": achieved / peak,
+                "frac_issued": issued / peak,
+                "frac_whole_step": float(n) * whole_mac_per_point / step_s / peak,
+                "peak_probes": {"count": PEAK_PROBES, "min": min(probes) / 1e12, "max": peak / 1e12,
+                                "note": "max of the probes, each one launch of >= 50 ms after a warm-up launch"},
                 "avg_launch_ms": acc_avg_s * 1e3,
                 "algorithmic_mac_per_point": nw * MADD_MULS * MAC_PER_MUL,
-                "traffic": (PMC_TRAFFIC_2_20["fetch_bytes"] + PMC_TRAFFIC_2_20["write_bytes"]) if args.log2n == LOG2_N else None,
+                "issued_mad_per_point": nw * MADD_MULS * MAD_ISSUED_PER_MUL,
+                "whole_step_mac_per_point": whole_mac_per_point,
+                "note": "frac credits 136 multiply-accumulates per field product (the 8-limb Montgomery count); the "
+                        "kernel works on plain residues and issues 81 v_mad_u64_u32 per product: frac_issued is the "
+                        "share of the multiplier's issue slots really used; frac_whole_step prices the whole MSM "
+                        "(all launches and the host's part, ms_per_step) at the bucket method's count per point",
+                "traffic": (PMC_TRAFFIC_2_20["fetch_bytes"] + PMC_TRAFFIC_2_20["write_bytes"]) if args.log2n == LOG2_N and args.scaling == "weak" else None,
                 "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc runs; see profiles/)",
                 "algorithmic_bytes": float(n) * nw * (64 + 4),
             },
@@ -282,7 +365,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n)
         if not args.no_range and world == 1:
-            out["range_proofs"] = range_proofs(ctx, local_rank)
+            out["range_proofs"] = range_proofs(ctx, local_rank, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_in_flight:
             out["msm_two_in_flight"] = msm_in_flight(bp, local_rank, dx, dy, dk, n, args.steps)
         assert res is not None

@@ -75,6 +75,11 @@ SIGNATURES = {
     "bp_msm_resident_plus": (ci, [vp, vp, sz, sz, vp, vp, vp, vp, vp, sz, vp]),
     "bp_msm_windows_dev": (ci, [vp, ci, vp, vp, vp, vp, sz, vp, C.POINTER(ci), C.POINTER(ci)]),
     "bp_msm_combine_windows_dev": (ci, [vp, ci, vp, ci, ci, ci, vp]),
+    "bp_msm_aos": (ci, [vp, ci, vp, vp, sz, vp]),
+    "bp_bases_register_aos": (ci, [vp, ci, vp, sz, C.POINTER(vp)]),
+    "bp_msm_shard_window_bits": (ci, [sz, ci]),
+    "bp_msm_shard_windows_dev": (ci, [vp, ci, vp, vp, vp, vp, sz, ci, vp, C.POINTER(ci)]),
+    "bp_msm_shard_windows_resident": (ci, [vp, vp, sz, sz, vp, ci, vp, C.POINTER(ci)]),
     "bp_inner_product": (ci, [vp, ci, vp, vp, sz, vp]),
     "bp_sum": (ci, [vp, ci, vp, sz, vp]),
     "bp_fold_scalars": (ci, [vp, ci, vp, vp, sz, vp, vp, vp]),

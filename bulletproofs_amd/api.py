@@ -50,6 +50,30 @@ def _pts(P):
     return x, y, inf
 
 
+AOS_STRIDE = 72
+
+
+def pack_aos(bases) -> np.ndarray:
+    """(x, y, inf) planes -> (n, 72)-byte records {x: 32, y: 32, infinity: 1, padding: 7}, the
+    memory image of a slice of arkworks short-Weierstrass Affine points over a 4-limb field"""
+    x, y, inf = _pts(bases)
+    n = x.shape[0]
+    rec = np.zeros((n, AOS_STRIDE), dtype=np.uint8)
+    rec[:, 0:32] = x.view(np.uint8).reshape(n, 32)
+    rec[:, 32:64] = y.view(np.uint8).reshape(n, 32)
+    if inf is not None:
+        rec[:, 64] = (inf != 0)
+    return rec
+
+
+def shard_window_bits(n_total: int, n_shards: int) -> int:
+    """window width every shard of an n_total-point MSM over n_shards ranges uses (host only)"""
+    c = lib.bp_msm_shard_window_bits(n_total, n_shards)
+    if c < 2:
+        raise BpError(c, "bp_msm_shard_window_bits: bad argument")
+    return c
+
+
 class Context:
     """One GPU + one stream (bp_ctx)."""
 
@@ -90,6 +114,20 @@ class Context:
         self._chk(lib.bp_msm(self.h, curve, _p(x), _p(y), _p(inf), _p(s), n, _p(out)))
         return out
 
+    def msm_aos(self, curve, records, scalars):
+        """bases as an (n, 72)-byte array of {x, y, infinity, padding} records (pack_aos)"""
+        rec = np.ascontiguousarray(records, dtype=np.uint8)
+        if rec.ndim != 2 or rec.shape[1] != AOS_STRIDE:
+            raise ValueError("records must be (n, 72) bytes")
+        s = _f(scalars)
+        n = min(rec.shape[0], s.shape[0])
+        out = np.zeros(12, dtype=np.uint64)
+        self._chk(lib.bp_msm_aos(self.h, curve, _p(rec), _p(s), n, _p(out)))
+        return out
+
+    def register_bases_aos(self, curve, records):
+        return Bases(self, curve, None, records=records)
+
     def msm_dev(self, curve, d_x, d_y, d_inf, d_s, n):
         out = np.zeros(12, dtype=np.uint64)
         self._chk(lib.bp_msm_dev(self.h, curve, d_x, d_y, d_inf, d_s, n, _p(out)))
@@ -107,6 +145,12 @@ class Context:
         nw, cb = C.c_int(), C.c_int()
         self._chk(lib.bp_msm_windows_dev(self.h, curve, d_x, d_y, d_inf, d_s, n, d_windows, C.byref(nw), C.byref(cb)))
         return nw.value, cb.value
+
+    def msm_shard_windows_dev(self, curve, d_x, d_y, d_inf, d_s, n, window_bits, d_windows):
+        """window sums of one shard of a multi-GPU MSM, at the width shard_window_bits gave"""
+        nw = C.c_int()
+        self._chk(lib.bp_msm_shard_windows_dev(self.h, curve, d_x, d_y, d_inf, d_s, n, window_bits, d_windows, C.byref(nw)))
+        return nw.value
 
     def msm_combine_windows_dev(self, curve, d_windows, n_parts, n_windows, window_bits):
         out = np.zeros(12, dtype=np.uint64)
@@ -286,10 +330,16 @@ class Context:
 class Bases:
     """Device-resident base points (bp_bases): the CRS uploaded once."""
 
-    def __init__(self, ctx: Context, curve, bases):
-        x, y, inf = _pts(bases)
+    def __init__(self, ctx: Context, curve, bases, records=None):
         h = C.c_void_p()
-        ctx._chk(lib.bp_bases_register(ctx.h, curve, _p(x), _p(y), _p(inf), x.shape[0], C.byref(h)))
+        if records is not None:
+            rec = np.ascontiguousarray(records, dtype=np.uint8)
+            if rec.ndim != 2 or rec.shape[1] != AOS_STRIDE:
+                raise ValueError("records must be (n, 72) bytes")
+            ctx._chk(lib.bp_bases_register_aos(ctx.h, curve, _p(rec), rec.shape[0], C.byref(h)))
+        else:
+            x, y, inf = _pts(bases)
+            ctx._chk(lib.bp_bases_register(ctx.h, curve, _p(x), _p(y), _p(inf), x.shape[0], C.byref(h)))
         self.ctx, self.h, self.curve = ctx, h, curve
 
     def __len__(self):
@@ -320,6 +370,16 @@ class Bases:
         self.ctx._chk(lib.bp_msm_resident_plus(self.ctx.h, self.h, offset, n, _p(s), _p(ex), _p(ey), _p(einf), _p(es), k,
                                                _p(out)))
         return out
+
+    def shard_windows(self, scalars, window_bits, d_windows, offset=0, n=None):
+        """window sums of this GPU's range of a sharded base set (bp_msm_shard_windows_resident)"""
+        s = _f(scalars)
+        if n is None:
+            n = s.shape[0]
+        nw = C.c_int()
+        self.ctx._chk(lib.bp_msm_shard_windows_resident(self.ctx.h, self.h, offset, n, _p(s), window_bits, d_windows,
+                                                        C.byref(nw)))
+        return nw.value
 
     def msm_pair(self, scalars_a, scalars_b, offset=0, n=None):
         """two sums over the same points in one pass (the A and S commitments of the range proofs)"""

@@ -21,7 +21,7 @@ using namespace bp;
 namespace {
 
 enum Slot {
-  S_IN0, S_IN1, S_IN2, S_IN3, S_IN4, S_IN5, S_IN6,
+  S_IN0, S_IN1, S_IN2, S_IN3, S_IN4, S_IN5, S_IN6, S_AOS,
   S_OUT0, S_OUT1, S_OUT2,
   S_KEYS_A, S_KEYS_B, S_VALS_A, S_VALS_B, S_SORT_TMP, S_BSTART, S_BEND, S_BUCKETS, S_SEGS,
   S_WINDOWS, S_TABLE, S_SMALL, S_NCH, S_CHOFF, S_SCAN_TMP, S_CHUNK_SUMS, S_HEAVY, S_CKEY_A, S_CKEY_B, S_CVAL_A, S_CVAL_B, S_DESC_B, S_DESC_S, S_CSORT_TMP, S_SEG_GROUPS, S_PACKED, S_RANGE, S_COUNT
@@ -502,10 +502,45 @@ int bp_msm(bp_ctx* ctx, int curve, const uint64_t* bases_x, const uint64_t* base
   return msm_full(ctx, curve, p0, p1, out_xyz);
 }
 
+int bp_msm_aos(bp_ctx* ctx, int curve, const void* bases, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
+  if (!ctx || !out_xyz || (n && (!bases || !scalars))) return fail(ctx, BP_E_ARG, "bp_msm_aos: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  void *raw, *dx, *dy, *di, *ds;
+  CHK(upload(ctx, S_AOS, bases, n * BP_AOS_STRIDE, &raw));
+  CHK(reserve(ctx, S_IN0, n * 32, &dx));
+  CHK(reserve(ctx, S_IN1, n * 32, &dy));
+  CHK(reserve(ctx, S_IN2, n, &di));
+  hipError_t e = launch_aos_split((const u32*)raw, n, (u32*)dx, (u32*)dy, (uint8_t*)di, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "aos_split", e);
+  CHK(upload(ctx, S_IN3, scalars, n * 32, &ds));
+  MsmPart p0{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)ds, n};
+  MsmPart p1{nullptr, nullptr, nullptr, nullptr, 0};
+  return msm_full(ctx, curve, p0, p1, out_xyz);
+}
+
+namespace {
+int bases_register_impl(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, const uint8_t* inf, const void* aos,
+                        size_t n, bp_bases** out);
+}
+
 int bp_bases_register(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, const uint8_t* inf, size_t n,
                       bp_bases** out) {
   if (!ctx || !out || (n && (!x || !y))) return fail(ctx, BP_E_ARG, "bp_bases_register: null argument");
   if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  return bases_register_impl(ctx, curve, x, y, inf, nullptr, n, out);
+}
+
+int bp_bases_register_aos(bp_ctx* ctx, int curve, const void* bases, size_t n, bp_bases** out) {
+  if (!ctx || !out || (n && !bases)) return fail(ctx, BP_E_ARG, "bp_bases_register_aos: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  return bases_register_impl(ctx, curve, nullptr, nullptr, nullptr, bases, n, out);
+}
+
+namespace {
+// planes (x, y, inf) or, when aos is given, n records of BP_AOS_STRIDE bytes split on the device
+int bases_register_impl(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, const uint8_t* inf, const void* aos,
+                        size_t n, bp_bases** out) {
   Guard g(ctx);
   bp_bases* b = new (std::nothrow) bp_bases();
   if (!b) return fail(ctx, BP_E_OOM, "host allocation");
@@ -530,7 +565,13 @@ int bp_bases_register(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t*
   if ((e = hipMalloc((void**)&b->x, bytes)) != hipSuccess || (e = hipMalloc((void**)&b->y, bytes)) != hipSuccess ||
       (e = hipMalloc((void**)&b->inf, n ? n : 1)) != hipSuccess)
     return fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "bp_bases_register: hipMalloc", e);
-  if (n) {
+  if (n && aos) {
+    void* raw;
+    CHK(upload(ctx, S_AOS, aos, n * BP_AOS_STRIDE, &raw));
+    e = launch_aos_split((const u32*)raw, n, b->x, b->y, b->inf, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "aos_split", e);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  } else if (n) {
     HIPCHK(ctx, hipMemcpyAsync(b->x, x, n * 32, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(b->y, y, n * 32, hipMemcpyHostToDevice, ctx->stream));
     if (inf)
@@ -543,6 +584,7 @@ int bp_bases_register(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t*
   *out = b;
   return BP_OK;
 }
+}  // namespace
 
 void bp_bases_free(bp_bases* b) {
   if (!b) return;
@@ -644,6 +686,28 @@ int bp_msm_resident_plus(bp_ctx* ctx, const bp_bases* bases, size_t offset, size
   return msm_full(ctx, bases->curve, p0, p1, out_xyz);
 }
 
+namespace {
+// window sums of one part copied to d_windows; window_bits 0 = the width the library picks for n
+int windows_to(bp_ctx* ctx, int curve, const MsmPart& p0, int window_bits, uint64_t* d_windows, int* n_windows,
+               int* window_bits_out) {
+  MsmPart p1{nullptr, nullptr, nullptr, nullptr, 0};
+  MsmPlan plan;
+  u32* d_win = nullptr;
+  const int saved = ctx->c_override;
+  if (window_bits) ctx->c_override = window_bits;
+  int rc = msm_device(ctx, curve, p0, p1, &plan, &d_win);
+  ctx->c_override = saved;
+  if (rc != BP_OK) return rc;
+  if (plan.n_windows > 64) return fail(ctx, BP_E_ARG, "msm windows: more than 64 windows; raise the window width");
+  HIPCHK(ctx, hipMemcpyAsync(d_windows, d_win, plan.win_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  msm_collect_times(ctx, p0.n != 0);
+  *n_windows = plan.n_windows;
+  if (window_bits_out) *window_bits_out = plan.c;
+  return BP_OK;
+}
+}  // namespace
+
 int bp_msm_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64_t* d_y, const uint8_t* d_inf,
                        const uint64_t* d_scalars, size_t n, uint64_t* d_windows, int* n_windows,
                        int* window_bits) {
@@ -652,17 +716,39 @@ int bp_msm_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64
   if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
   Guard g(ctx);
   MsmPart p0{(const u32*)d_x, (const u32*)d_y, d_inf, (const u32*)d_scalars, n};
-  MsmPart p1{nullptr, nullptr, nullptr, nullptr, 0};
-  MsmPlan plan;
-  u32* d_win = nullptr;
-  CHK(msm_device(ctx, curve, p0, p1, &plan, &d_win));
-  if (plan.n_windows > 64) return fail(ctx, BP_E_ARG, "bp_msm_windows_dev: more than 64 windows; raise the window width");
-  HIPCHK(ctx, hipMemcpyAsync(d_windows, d_win, plan.win_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  msm_collect_times(ctx, n != 0);
-  *n_windows = plan.n_windows;
-  *window_bits = plan.c;
-  return BP_OK;
+  return windows_to(ctx, curve, p0, 0, d_windows, n_windows, window_bits);
+}
+
+int bp_msm_shard_window_bits(size_t n_total, int n_shards) {
+  if (n_shards < 1) return BP_E_ARG;
+  // the largest shard of a split into ranges whose sizes differ by at most one
+  const size_t largest = n_total / (size_t)n_shards + (n_total % (size_t)n_shards ? 1 : 0);
+  return msm_default_window(largest);
+}
+
+int bp_msm_shard_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64_t* d_y, const uint8_t* d_inf,
+                             const uint64_t* d_scalars, size_t n, int window_bits, uint64_t* d_windows, int* n_windows) {
+  if (!ctx || !d_windows || !n_windows || (n && (!d_x || !d_y || !d_scalars)))
+    return fail(ctx, BP_E_ARG, "bp_msm_shard_windows_dev: null argument");
+  if (window_bits < 2 || window_bits > 20) return fail(ctx, BP_E_ARG, "bp_msm_shard_windows_dev: window_bits outside 2..20");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  MsmPart p0{(const u32*)d_x, (const u32*)d_y, d_inf, (const u32*)d_scalars, n};
+  return windows_to(ctx, curve, p0, window_bits, d_windows, n_windows, nullptr);
+}
+
+int bp_msm_shard_windows_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n, const uint64_t* scalars,
+                                  int window_bits, uint64_t* d_windows, int* n_windows) {
+  if (!ctx || !bases || !d_windows || !n_windows || (n && !scalars))
+    return fail(ctx, BP_E_ARG, "bp_msm_shard_windows_resident: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_msm_shard_windows_resident: bases belong to another context");
+  if (offset > bases->n || n > bases->n - offset) return fail(ctx, BP_E_ARG, "bp_msm_shard_windows_resident: range outside bases");
+  if (window_bits < 2 || window_bits > 20) return fail(ctx, BP_E_ARG, "bp_msm_shard_windows_resident: window_bits outside 2..20");
+  Guard g(ctx);
+  void* ds;
+  CHK(upload(ctx, S_IN3, scalars, n * 32, &ds));
+  MsmPart p0{bases->x + offset * 8, bases->y + offset * 8, bases->inf + offset, (const u32*)ds, n};
+  return windows_to(ctx, bases->curve, p0, window_bits, d_windows, n_windows, nullptr);
 }
 
 int bp_msm_combine_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_windows, int n_parts, int n_windows,

@@ -192,4 +192,32 @@ hipError_t launch_normalize_jac(int curve, const u32* xyz, size_t n, u32* ox, u3
   return hipGetLastError();
 }
 
+// Array of 72-byte affine records {x: 8 u32, y: 8 u32, infinity: 1 byte, 7 bytes of padding} ->
+// the x, y and infinity planes the pipeline reads.  One lane per 32-bit word: the reads are
+// contiguous over the whole array and each plane's writes are contiguous over a record's words.
+__global__ __launch_bounds__(256) void k_aos_split(const u32* __restrict__ aos, size_t n, u32* __restrict__ x,
+                                                   u32* __restrict__ y, uint8_t* __restrict__ inf) {
+  const size_t words = n * 18;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < words; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = t / 18;
+    const u32 w = (u32)(t % 18);
+    if (w >= 17) continue;  // padding
+    const u32 v = aos[t];
+    if (w < 8)
+      x[i * 8 + w] = v;
+    else if (w < 16)
+      y[i * 8 + (w - 8)] = v;
+    else
+      inf[i] = (v & 0xffu) ? 1 : 0;
+  }
+}
+
+hipError_t launch_aos_split(const u32* aos, size_t n, u32* x, u32* y, uint8_t* inf, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  size_t blocks = (n * 18 + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_aos_split, dim3((unsigned)blocks), dim3(256), 0, st, aos, n, x, y, inf);
+  return hipGetLastError();
+}
+
 }  // namespace bp

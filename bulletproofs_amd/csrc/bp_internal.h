@@ -96,6 +96,8 @@ hipError_t launch_window_tables(int curve, const u32* px, const u32* py, const u
                                 int n_windows, u32* table, hipStream_t st);
 hipError_t launch_normalize_jac(int curve, const u32* xyz, size_t n, u32* ox, u32* oy, uint8_t* oinf,
                                 hipStream_t st);
+// n records of 72 bytes {x, y, infinity byte, padding} -> planes
+hipError_t launch_aos_split(const u32* aos, size_t n, u32* x, u32* y, uint8_t* inf, hipStream_t st);
 
 // ---- MSM (bp_msm.hip) ----
 struct MsmPart {
@@ -158,6 +160,7 @@ struct MsmPipe {
 };
 
 int msm_choose_window(size_t n);
+int msm_default_window(size_t n);
 hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride = 0,
                          bool allow_stages = false);
 

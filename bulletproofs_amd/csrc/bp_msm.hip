@@ -81,6 +81,14 @@ int msm_choose_window(size_t n) {
   return 4;
 }
 
+// width msm_make_plan picks for one sum over n points with no override and no window tables
+int msm_default_window(size_t n) {
+  // below kSmallMaxPoints the one-launch front end and the tree kernels apply, and 8-bit
+  // windows (128 buckets, no short top window) are fastest from 2^9 points up
+  if (n > 0 && n <= kSmallMaxPoints && !getenv("BP_MSM_NO_SMALL")) return n >= 512 ? 8 : 4;
+  return msm_choose_window(n);
+}
+
 static int key_bits_for(u32 max_key) {
   int b = 1;
   while ((1ull << b) <= max_key) b++;
@@ -94,8 +102,6 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   p.groups = groups;
   p.tab = table_stride != 0 && n_total > 0;
   p.c = (c_override >= 2 && c_override <= 20) ? c_override : msm_choose_window(n_total / groups);
-  // below kSmallMaxPoints the one-launch front end and the tree kernels apply, and 8-bit
-  // windows (128 buckets, no short top window) are fastest from 2^9 points up
   const bool small_ok = n_total > 0 && n_total <= kSmallMaxPoints && !getenv("BP_MSM_NO_SMALL");
   if (small_ok && !(c_override >= 2 && c_override <= 20)) p.c = n_total / groups >= 512 ? 8 : 4;
   if (p.tab) p.c = kTableWindowBits;

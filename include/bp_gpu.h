@@ -83,6 +83,16 @@ int bp_set_msm_window(bp_ctx* ctx, int c);
 int bp_msm(bp_ctx* ctx, int curve, const uint64_t* bases_x, const uint64_t* bases_y,
            const uint8_t* bases_inf, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]);
 
+/* As bp_msm with the bases as an array of structures: n records of BP_AOS_STRIDE bytes
+ * {x: 4 u64, y: 4 u64, infinity: 1 byte (non-zero = identity), 7 bytes of padding}, the in-memory
+ * value of ark_ec::short_weierstrass::Affine<P> over a 4-limb base field as rustc lays it out
+ * today (a shim asserts size_of::<Affine<P>>() == 72 and the three offset_of! values once).  The
+ * slice `&[G]` that Msm::execute hands to msm_unchecked (src/msm.rs:79-87) is passed as it is; the
+ * planes are separated on the device after one contiguous upload. */
+#define BP_AOS_STRIDE 72
+int bp_msm_aos(bp_ctx* ctx, int curve, const void* bases, const uint64_t* scalars, size_t n,
+               uint64_t out_xyz[12]);
+
 /* Same with every input already in device memory (scalars: n*4 u64). */
 int bp_msm_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64_t* d_y,
                const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, uint64_t out_xyz[12]);
@@ -98,6 +108,9 @@ int bp_msm2_dev(bp_ctx* ctx, int curve, const uint64_t* d_x0, const uint64_t* d_
  * poly_commit CRS) is static, so it is uploaded once. */
 int bp_bases_register(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y,
                       const uint8_t* inf, size_t n, bp_bases** out);
+/* bp_bases_register from an array of BP_AOS_STRIDE-byte records (see bp_msm_aos): `crs.gs`,
+ * `crs.hs` (src/ipa/types.rs:10-14) handed over as the Vec<G> they are. */
+int bp_bases_register_aos(bp_ctx* ctx, int curve, const void* bases, size_t n, bp_bases** out);
 void bp_bases_free(bp_bases* b);
 size_t bp_bases_len(const bp_bases* b);
 /* Optional: builds window tables for a registered base set (2^(8w) * P for w < 32: 2 KiB per
@@ -145,6 +158,26 @@ int bp_msm_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64
                        uint64_t* d_windows, int* n_windows, int* window_bits);
 int bp_msm_combine_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_windows, int n_parts,
                                int n_windows, int window_bits, uint64_t out_xyz[12]);
+/* One MSM split over several GPUs (one context per GPU, one process or thread per context): the
+ * points are cut into n_shards contiguous ranges whose sizes differ by at most one, every shard
+ * computes its window sums with the SAME window width, the caller exchanges the n_windows * 128
+ * bytes per shard (an all-gather over RCCL, or peer copies) and any shard finishes with
+ * bp_msm_combine_windows_dev.  The sum over ranges of Msm::execute, src/msm.rs:84-87; the
+ * reference itself runs one sum on one host.
+ *  - bp_msm_shard_window_bits: the common width, a function of the total and the shard count only
+ *    (the width the library would pick for the largest shard), so every rank computes it alone.
+ *    Needs no context and no GPU.  Returns the width (>= 2) or BP_E_ARG.
+ *  - bp_msm_shard_windows_dev: window sums of one shard whose inputs are in device memory, with
+ *    that width; n may be 0 (all sums are the identity).
+ *  - bp_msm_shard_windows_resident: the same over a range of a base set registered on this
+ *    context's GPU (a CRS is registered shard by shard, each GPU holding its range), host scalars. */
+int bp_msm_shard_window_bits(size_t n_total, int n_shards);
+int bp_msm_shard_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const uint64_t* d_y,
+                             const uint8_t* d_inf, const uint64_t* d_scalars, size_t n, int window_bits,
+                             uint64_t* d_windows, int* n_windows);
+int bp_msm_shard_windows_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
+                                  const uint64_t* scalars, int window_bits, uint64_t* d_windows,
+                                  int* n_windows);
 
 /* ---- field-vector kernels (host buffers) --------------------------------- */
 

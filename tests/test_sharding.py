@@ -1,16 +1,15 @@
-"""CPU test of the N > 1 path: 2 ranks over gloo shard an MSM by point range,
-all-gather their partial sums and combine; the per-rank MSM and the combine are
-oracle-backed stand-ins here (the device versions are covered by the GPU tests)."""
+"""CPU tests of the N > 1 path: 2 ranks over gloo shard an MSM by point range, all-gather
+their per-window partial sums and combine.  The per-rank window sums and the combine are
+oracle-backed stand-ins here that follow the device format (n_windows XYZZ points of 16 u64 at
+the common window width); the device versions are covered by the GPU tests."""
 import os
 import sys
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-import bp_oracle as o
 from conftest import ROOT
 
 
@@ -26,53 +25,99 @@ def test_shard_ranges_cover():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _worker(rank, world, port, q):
+def test_shard_window_width_is_a_function_of_the_total_alone():
+    """every rank derives the same width without talking to the others, also where the shard
+    sizes straddle a threshold of the single-GPU choice (511 | 512, 2^18 - 1 | 2^18)"""
+    from bulletproofs_amd.api import shard_window_bits
+
+    assert shard_window_bits(1 << 20, 1) == 16
+    assert shard_window_bits(1 << 21, 8) == 16
+    assert shard_window_bits((1 << 19) - 1, 2) == 16   # shards of 2^18 and 2^18 - 1 points
+    assert shard_window_bits((1 << 19) - 2, 2) == 8
+    assert shard_window_bits(1023, 2) == 8             # shards of 512 and 511 points
+    assert shard_window_bits(1022, 2) == 4
+    assert shard_window_bits(3, 4) == 4                # some shards are empty
+    assert shard_window_bits(0, 2) >= 2
+
+
+def _worker(rank, world, port, n, q):
+    try:
+        _worker_body(rank, world, port, n, q)
+    except BaseException as exc:  # the parent would otherwise wait for its timeout
+        q.put((rank, repr(exc), -1))
+        raise
+
+
+def _worker_body(rank, world, port, n, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import bp_oracle as oo
+    import c_oracle
     from bulletproofs_amd.sharded import ShardedMsm, shard_range
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     c = oo.SECP256K1
-    n = 50
+    co = c_oracle.COracle()
     rng = oo.SplitMix64(77)
-    pts = oo.gen_points_arith(n, 5, 9, c)
     ks = rng.scalars(n, c.n)
+    g = oo.pack_field([c.g[0], c.g[1]], c.p).reshape(8)
+    px, py = co.gen_points(c.id, g, g, max(n, 1))
     b, e = shard_range(n, rank, world)
+    one = oo.pack_field([1], c.p).reshape(4)
+    seen = {}
 
-    def local_windows(d_x, d_y, d_inf, d_s, n_local, out):
-        # stand-in for bp_msm_windows_dev: one "window" holding this rank's partial sum (XYZZ, zz=zzz=1)
-        P = oo.msm_naive(pts[b:e], ks[b:e], c)
-        vals = [0, 0, 0, 0] if P is None else [P[0], P[1], 1, 1]
-        arr = oo.pack_field(vals, c.p).reshape(-1).view(np.int64)
-        out[:16] = torch.from_numpy(arr.copy())
-        return 1, 16
+    def local_windows(d_x, d_y, d_inf, d_s, n_local, window_bits, out):
+        # stand-in for bp_msm_shard_windows_dev: window w holds sum_i digit_w(k_i) P_i over this rank's range
+        assert n_local == e - b
+        seen["bits"] = window_bits
+        nw = (256 + window_bits - 1) // window_bits
+        for w in range(nw):
+            digits = [(k >> (window_bits * w)) & ((1 << window_bits) - 1) for k in ks[b:e]]
+            xyz = co.msm(c.id, (px[b:e], py[b:e], None), oo.pack_field(digits, c.n), 1) if e > b else np.zeros(12, np.uint64)
+            win = np.zeros((4, 4), dtype=np.uint64)
+            if xyz[8:].any():
+                win[0], win[1], win[2], win[3] = xyz[0:4], xyz[4:8], one, one
+            out[w * 16:(w + 1) * 16] = torch.from_numpy(win.reshape(-1).view(np.int64).copy())
+        return nw
 
     def combine(gathered, w, nw, cb):
         acc = None
-        for r in range(w):
-            x, y, zz, zzz = oo.unpack_field(gathered[r, :16].numpy().view(np.uint64).reshape(4, 4), c.p)
-            acc = oo.add(acc, None if zz == 0 else (x, y), c)
+        for win in reversed(range(nw)):
+            for _ in range(cb):
+                acc = oo.add(acc, acc, c)
+            for r in range(w):
+                x, y, zz, zzz = oo.unpack_field(gathered[r, win * 16:(win + 1) * 16].numpy().view(np.uint64).reshape(4, 4), c.p)
+                acc = oo.add(acc, None if zz == 0 else (x, y), c)
         return acc
 
-    sm = ShardedMsm(None, c.id, dist=dist, device="cpu", local_windows=local_windows, combine=combine)
+    sm = ShardedMsm(None, c.id, dist=dist, device="cpu", local_windows=local_windows, combine=combine, n_total=n)
     got = sm.msm(None, None, None, None, e - b)
-    q.put((rank, got == oo.msm_naive(pts, ks, c)))
+    exp = co.msm(c.id, (px[:n], py[:n], None), oo.pack_field(ks, c.n), 2)
+    exp_pt = None if not exp[8:].any() else tuple(oo.unpack_field(exp[:8].reshape(2, 4), c.p))
+    q.put((rank, got == exp_pt, seen["bits"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_shard_gather_combine():
-    world = 2
+def _run(world, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in range(world)]
+    results = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(results) == [(0, True), (1, True)]
+    return sorted(results)
+
+
+def test_two_rank_gloo_shard_gather_combine():
+    assert _run(2, 50) == [(0, True, 4), (1, True, 4)]
+
+
+def test_two_rank_gloo_shards_straddling_a_width_threshold():
+    # 512 and 511 points: alone, the ranks would pick 8- and 4-bit windows
+    assert _run(2, 1023) == [(0, True, 8), (1, True, 8)]
