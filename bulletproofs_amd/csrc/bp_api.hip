@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "bp_host_math.h"
@@ -143,7 +144,9 @@ struct bp_ipa {
   const uint8_t *ginf = nullptr, *hinf = nullptr;
   void* block = nullptr;             // one allocation behind every pointer below up to `dots`
   size_t block_bytes = 0;
-  u32 *a = nullptr, *b = nullptr;    // folded in place
+  u32 *a = nullptr, *b = nullptr;    // current vectors (folded in place, or out of place into a2, b2 and swapped)
+  u32 *a2 = nullptr, *b2 = nullptr;  // n0/2 elements each: the other side of the out-of-place fold
+  bool prepped = false;              // the last fold already wrote this round's dots and MSM scalars
   u32 *cg = nullptr, *ch = nullptr;  // n0 coefficients each
   u32 *eg = nullptr, *eh = nullptr;  // n0 cross-term scalars each
   u32* u_xy = nullptr;               // the point u (x|y) when has_u
@@ -268,14 +271,12 @@ void range_tables(const uint64_t z[4], size_t m, unsigned n_bits, uint64_t* zpow
   }
 }
 
+// sum_w 2^(c*w) win[w] on the host (c = 0: the plain sum), normalised: the sequential tail of every MSM
 void finish_windows(int curve, const uint64_t* win, int n_windows, int c, uint64_t out_xyz[12]) {
-  if (curve == BP_SECP256K1) {
-    auto r = host::hx_combine_windows<Secp256k1Fq>(win, n_windows, c);
-    host::hx_to_xyz<Secp256k1Fq>(r, out_xyz);
-  } else {
-    auto r = host::hx_combine_windows<VestaFq>(win, n_windows, c);
-    host::hx_to_xyz<VestaFq>(r, out_xyz);
-  }
+  if (curve == BP_SECP256K1)
+    host::hj_combine_windows<host::SecpPlainOps>(win, n_windows, c, out_xyz);
+  else
+    host::hj_combine_windows<host::MontOps<VestaFq>>(win, n_windows, c, out_xyz);
 }
 
 // device phase of an MSM: leaves plan->n_windows XYZZ window sums in S_WINDOWS
@@ -346,7 +347,7 @@ int msm_full(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, uint6
   HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   msm_collect_times(ctx, plan.n_total != 0);
-  finish_windows(curve, (const uint64_t*)ctx->pinned, plan.n_windows, plan.c, out_xyz);
+  finish_windows(curve, (const uint64_t*)ctx->pinned, plan.n_windows, plan.finish_c, out_xyz);
   return BP_OK;
 }
 
@@ -653,7 +654,7 @@ int bp_msm_resident_pair(bp_ctx* ctx, const bp_bases* bases, size_t offset, size
   HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   msm_collect_times(ctx, plan.n_total != 0);
-  const int curve = bases->curve, gw = plan.group_windows, c = plan.c;
+  const int curve = bases->curve, gw = plan.group_windows, c = plan.finish_c;
   const uint64_t* win = (const uint64_t*)ctx->pinned;
   const uint64_t* win_b = win + (size_t)gw * 16;
   const bool helped = ctx->worker.submit([=] { finish_windows(curve, win_b, gw, c, out_b_xyz); });
@@ -1200,7 +1201,7 @@ namespace {
 // Everything a session owns on the device lives in one block, so a prove costs one
 // allocation; a freed block is parked on the context for the next session.
 struct IpaLayout {
-  size_t gx, gy, ginf, hx, hy, hinf, a, b, cg, ch, eg, eh, u, dots, total;
+  size_t gx, gy, ginf, hx, hy, hinf, a, b, a2, b2, cg, ch, eg, eh, u, dots, total;
 };
 
 IpaLayout ipa_layout(size_t n, bool has_h, bool owns_gens) {
@@ -1216,6 +1217,7 @@ IpaLayout ipa_layout(size_t n, bool has_h, bool owns_gens) {
     if (has_h) { l.hx = take(n * 32); l.hy = take(n * 32); l.hinf = take(n); }
   }
   l.a = take(n * 32); l.b = take(n * 32);
+  l.a2 = take(n * 16 + 32); l.b2 = take(n * 16 + 32);
   l.cg = take(n * 32); l.eg = take(n * 32);
   if (has_h) { l.ch = take(n * 32); l.eh = take(n * 32); }
   l.u = take(64);
@@ -1275,7 +1277,7 @@ int ipa_begin_common(bp_ctx* ctx, int curve, int variant, const bp_bases* res, s
   s->block = blk;
   char* base = (char*)blk;
   auto at = [&](size_t off) { return (u32*)(base + off); };
-  s->a = at(l.a); s->b = at(l.b); s->cg = at(l.cg); s->eg = at(l.eg);
+  s->a = at(l.a); s->b = at(l.b); s->a2 = at(l.a2); s->b2 = at(l.b2); s->cg = at(l.cg); s->eg = at(l.eg);
   if (has_h) { s->ch = at(l.ch); s->eh = at(l.eh); }
   s->u_xy = at(l.u);
   s->dots = at(l.dots);
@@ -1377,6 +1379,7 @@ int bp_ipa_set_u(bp_ipa* s, const uint64_t u_xy[8]) {
   Guard g(ctx);
   s->has_u = false;
   s->u_scaled = false;
+  s->prepped = false;  // the scalars of u are part of what a fold prepares
   if (!u_xy) return BP_OK;
   HIPCHK(ctx, hipMemcpyAsync(s->u_xy, u_xy, 64, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1397,6 +1400,7 @@ int bp_ipa_set_u_resident(bp_ipa* s, size_t u_index, const uint64_t factor[4]) {
   HIPCHK(ctx, hipMemcpyAsync(&inf, s->res->inf + u_index, 1, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   s->has_u = s->u_scaled = false;
+  s->prepped = false;
   if (inf) return BP_OK;  // a multiple of the identity adds nothing
   s->u_index = u_index;
   s->u_factor = to_arg(factor);
@@ -1421,7 +1425,10 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
   u32* part_r = part_l + (size_t)kDotBlocks * 8;
   u32 *d_cl = part_r + (size_t)kDotBlocks * 8, *d_cr = d_cl + 8, *d_scaled = d_cl + 16;
   hipError_t e;
-  if (h <= kIpaPrepMaxHalf) {
+  if (s->prepped) {
+    // the fold that led here left c_l, c_r and the MSM scalars of this round (k_ipa_fold_prep)
+    s->prepped = false;
+  } else if (h <= kIpaPrepMaxHalf) {
     // short vectors: a round is a chain of launches, so dots, scaling and MSM scalars share one
     const bool scaled = s->has_u && s->u_scaled;
     e = launch_ipa_round_prep(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, n0, h,
@@ -1473,7 +1480,7 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
   msm_collect_times(ctx, true);
   const uint64_t* win = (const uint64_t*)host;
   {
-    const int curve = s->curve, gw = plan.group_windows, c = plan.c;
+    const int curve = s->curve, gw = plan.group_windows, c = plan.finish_c;
     const uint64_t* win_r = win + (size_t)gw * 16;
     const bool helped = ctx->worker.submit([=] { finish_windows(curve, win_r, gw, c, r_xyz); });
     finish_windows(curve, win, gw, c, l_xyz);
@@ -1503,8 +1510,21 @@ int bp_ipa_round_fold(bp_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]) {
   // The same launch folds the scalars; outputs overwrite the low halves in place (output i reads
   // only inputs i and i+h): a' = a_lo*x + a_hi*x^-1, b' = b_lo*x^-1 + b_hi*x (src/ipa/mod.rs:88-89;
   // src/poly_commit/mod.rs:96-97 writes the same pair as a_hi*u^-1 + a_lo*u, b_lo*u^-1 + b_hi*u)
-  e = launch_ipa_round_fold(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, s->n0, h, xm, xim, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_round_fold", e);
+  if (h >= 2 && h / 2 <= kIpaPrepMaxHalf && h * 2 <= s->n0) {
+    // short vectors, and not the first fold (a2, b2 hold n0/2 elements): fold out of place and
+    // prepare the next round in the same launch; bp_ipa_round_lr then goes straight to its MSM
+    const bool scaled = s->has_u && s->u_scaled;
+    u32* d_cl = s->dots + (size_t)2 * kDotBlocks * 8;
+    e = launch_ipa_fold_prep(s->curve, s->a, s->b, s->a2, s->b2, s->cg, has_h ? s->ch : nullptr, s->n0, h, xm, xim,
+                             scaled ? s->u_factor : FeArg{}, scaled ? 1 : 0, s->eg, s->eh, d_cl, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_fold_prep", e);
+    std::swap(s->a, s->a2);
+    std::swap(s->b, s->b2);
+    s->prepped = true;
+  } else {
+    e = launch_ipa_round_fold(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, s->n0, h, xm, xim, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_round_fold", e);
+  }
   s->x_canon.push_back(xc);
   s->xinv_canon.push_back(xic);
   s->n = h;
@@ -1546,8 +1566,8 @@ int bp_ipa_read(bp_ipa* s, uint64_t* gx, uint64_t* gy, uint8_t* ginf, uint64_t* 
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t* win = (const uint64_t*)ctx->pinned;
     uint64_t g_xyz[12], h_xyz[12];
-    finish_windows(s->curve, win, plan.group_windows, plan.c, g_xyz);
-    finish_windows(s->curve, win + (size_t)plan.group_windows * 16, plan.group_windows, plan.c, h_xyz);
+    finish_windows(s->curve, win, plan.group_windows, plan.finish_c, g_xyz);
+    finish_windows(s->curve, win + (size_t)plan.group_windows * 16, plan.group_windows, plan.finish_c, h_xyz);
     auto put = [](const uint64_t xyz[12], uint64_t* ox, uint64_t* oy, uint8_t* oinf) {
       bool inf = !(xyz[8] | xyz[9] | xyz[10] | xyz[11]);
       // affine outputs encode the identity as x = y = 0 with the flag set

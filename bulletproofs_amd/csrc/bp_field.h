@@ -37,6 +37,33 @@ BP_DEV void fe_store(uint32_t* p, const Fe& a) {
   q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
 }
 
+// streaming forms: data that is read or written once should not displace what the caches hold
+BP_DEV Fe fe_load_nt(const uint32_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  const v4u* q = reinterpret_cast<const v4u*>(p);
+  v4u lo = __builtin_nontemporal_load(q), hi = __builtin_nontemporal_load(q + 1);
+  Fe r;
+  r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+  r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+  return r;
+#else
+  return fe_load(p);
+#endif
+}
+
+BP_DEV void fe_store_nt(uint32_t* p, const Fe& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  v4u* q = reinterpret_cast<v4u*>(p);
+  v4u lo = {a.v[0], a.v[1], a.v[2], a.v[3]}, hi = {a.v[4], a.v[5], a.v[6], a.v[7]};
+  __builtin_nontemporal_store(lo, q);
+  __builtin_nontemporal_store(hi, q + 1);
+#else
+  fe_store(p, a);
+#endif
+}
+
 BP_DEV Fe fe_zero() {
   Fe r;
 #pragma unroll
@@ -86,6 +113,22 @@ BP_DEV Fe fe_reduce_once(const Fe& a, uint32_t carry) {
   for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(a.v[i], F::mod(i), bw, &bw);
   bool keep = F::kFullWidth ? (carry == 0 && bw != 0) : (bw != 0);
   return fe_select(keep, a, d);
+}
+
+// carry * 2^256 + a, below 3p, brought below p (the dual product's tail)
+template <class F>
+BP_DEV Fe fe_reduce_twice(Fe a, uint32_t carry) {
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    Fe d;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(a.v[i], F::mod(i), bw, &bw);
+    const bool ge = carry != 0 || bw == 0;
+    a = fe_select(ge, d, a);
+    carry = ge ? carry - bw : carry;
+  }
+  return a;
 }
 
 template <class F>
@@ -248,6 +291,16 @@ BP_DEV Fe fe_mul<Secp256k1FqP>(const Fe& a, const Fe& b) {
   return fe_mul_plain_secp_portable(a, b);
 }
 #endif
+
+// a*b + c*d (Montgomery form in and out): one reduction for both products on the device
+template <class F>
+BP_DEV Fe fe_mul2(const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return fe_mul2_dev<F>(a, b, c, d);
+#else
+  return fe_add<F>(fe_mul<F>(a, b), fe_mul<F>(c, d));
+#endif
+}
 
 template <class F>
 BP_DEV Fe fe_sqr(const Fe& a) {

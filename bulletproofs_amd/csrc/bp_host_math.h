@@ -42,40 +42,54 @@ inline void h_sub_mod(HFe& a) {
     br = (d >> 64) & 1;
   }
 }
+// a + b + carry-in -> low 64 bits, carry-out in *c (0 or 1); likewise the borrow chain
+inline uint64_t h_adc(uint64_t a, uint64_t b, uint64_t* c) {
+  uint64_t s, t;
+  uint64_t c1 = __builtin_add_overflow(a, b, &s);
+  uint64_t c2 = __builtin_add_overflow(s, *c, &t);
+  *c = c1 | c2;
+  return t;
+}
+inline uint64_t h_sbb(uint64_t a, uint64_t b, uint64_t* br) {
+  uint64_t d, t;
+  uint64_t b1 = __builtin_sub_overflow(a, b, &d);
+  uint64_t b2 = __builtin_sub_overflow(d, *br, &t);
+  *br = b1 | b2;
+  return t;
+}
+// (carry * 2^256 + s) mod p for a value below 2p: one subtraction, chosen without a branch
 template <class F>
-inline HFe h_add(const HFe& a, const HFe& b) {
+inline HFe h_reduce_once(const HFe& s, uint64_t carry) {
+  HFe d;
+  uint64_t br = 0;
+  for (int i = 0; i < 4; i++) d.v[i] = h_sbb(s.v[i], F::mod64(i), &br);
+  const uint64_t keep = (uint64_t)0 - (uint64_t)((carry == 0) & (br != 0));  // all ones: s < p
   HFe r;
-  u128 c = 0;
-  for (int i = 0; i < 4; i++) {
-    c += (u128)a.v[i] + b.v[i];
-    r.v[i] = (uint64_t)c;
-    c >>= 64;
-  }
-  if (c || h_geq_mod<F>(r)) h_sub_mod<F>(r);
+  for (int i = 0; i < 4; i++) r.v[i] = (s.v[i] & keep) | (d.v[i] & ~keep);
   return r;
 }
 template <class F>
+inline HFe h_add(const HFe& a, const HFe& b) {
+  HFe s;
+  uint64_t c = 0;
+  for (int i = 0; i < 4; i++) s.v[i] = h_adc(a.v[i], b.v[i], &c);
+  return h_reduce_once<F>(s, c);
+}
+template <class F>
 inline HFe h_sub(const HFe& a, const HFe& b) {
-  HFe r;
-  u128 br = 0;
-  for (int i = 0; i < 4; i++) {
-    u128 d = (u128)a.v[i] - b.v[i] - (uint64_t)br;
-    r.v[i] = (uint64_t)d;
-    br = (d >> 64) & 1;
-  }
-  if (br) {
-    u128 c = 0;
-    for (int i = 0; i < 4; i++) {
-      c += (u128)r.v[i] + F::mod64(i);
-      r.v[i] = (uint64_t)c;
-      c >>= 64;
-    }
-  }
+  HFe d, r;
+  uint64_t br = 0, c = 0;
+  for (int i = 0; i < 4; i++) d.v[i] = h_sbb(a.v[i], b.v[i], &br);
+  const uint64_t mask = (uint64_t)0 - br;  // all ones when a < b: add p back
+  for (int i = 0; i < 4; i++) r.v[i] = h_adc(d.v[i], F::mod64(i) & mask, &c);
   return r;
 }
 template <class F>
 inline HFe h_dbl(const HFe& a) {
-  return h_add<F>(a, a);
+  HFe s;
+  s.v[0] = a.v[0] << 1;
+  for (int i = 1; i < 4; i++) s.v[i] = (a.v[i] << 1) | (a.v[i - 1] >> 63);
+  return h_reduce_once<F>(s, a.v[3] >> 63);
 }
 template <class F>
 inline HFe h_mul(const HFe& a, const HFe& b) {
@@ -328,6 +342,204 @@ inline void hx_combine_windows2(const uint64_t* win_a, const uint64_t* win_b, in
   }
   *out_a = a;
   *out_b = b;
+}
+
+// ---- window combination on Jacobian coordinates -------------------------------------------
+// The combine is a chain of (256 - c) doublings: its time is the host's share of every MSM.  A
+// Jacobian doubling with a = 0 is 2M + 5S against the 6M + 3S of an XYZZ doubling, and for
+// secp256k1 the chain runs on plain residues, where p = 2^256 - 0x1000003D1 turns the reduction of
+// a 512-bit product into two multiplications by a 33-bit constant and a squaring needs 10 limb
+// products instead of 16.  The window sums arrive as XYZZ points in Montgomery form; the result
+// leaves as a normalised Montgomery-form point, as before.
+
+// field operations of the chain: generic Montgomery form
+template <class F>
+struct MontOps {
+  typedef F Field;
+  static HFe mul(const HFe& a, const HFe& b) { return h_mul<F>(a, b); }
+  static HFe sqr(const HFe& a) { return h_mul<F>(a, a); }
+  static HFe import(const HFe& mont) { return mont; }
+  static HFe to_mont(const HFe& v) { return v; }
+};
+
+// secp256k1 base field on plain residues
+struct SecpPlainOps {
+  typedef Secp256k1Fq Field;
+  static HFe reduce512(const uint64_t t[8]) {
+    const uint64_t C = 0x1000003D1ull;  // 2^256 mod p
+    uint64_t r[4];
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (u128)t[4 + i] * C + t[i];
+      r[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    // what is left above 2^256 (below 2^34) folds once more, and a carry out of that a last time
+    c = (u128)(uint64_t)c * C + r[0];
+    r[0] = (uint64_t)c;
+    c >>= 64;
+    for (int i = 1; i < 4; i++) {
+      c += r[i];
+      r[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    if (c) {
+      c = (u128)r[0] + C;
+      r[0] = (uint64_t)c;
+      c >>= 64;
+      for (int i = 1; i < 4; i++) {
+        c += r[i];
+        r[i] = (uint64_t)c;
+        c >>= 64;
+      }
+    }
+    HFe out{{r[0], r[1], r[2], r[3]}};
+    if (h_geq_mod<Secp256k1Fq>(out)) h_sub_mod<Secp256k1Fq>(out);
+    return out;
+  }
+  static HFe mul(const HFe& a, const HFe& b) {
+    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+      u128 c = 0;
+      for (int j = 0; j < 4; j++) {
+        c += (u128)a.v[j] * b.v[i] + t[i + j];
+        t[i + j] = (uint64_t)c;
+        c >>= 64;
+      }
+      t[i + 4] = (uint64_t)c;
+    }
+    return reduce512(t);
+  }
+  static HFe sqr(const HFe& a) {
+    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u128 c;
+    // the six cross products once ...
+    c = (u128)a.v[0] * a.v[1];
+    t[1] = (uint64_t)c;
+    c >>= 64;
+    c += (u128)a.v[0] * a.v[2];
+    t[2] = (uint64_t)c;
+    c >>= 64;
+    c += (u128)a.v[0] * a.v[3];
+    t[3] = (uint64_t)c;
+    t[4] = (uint64_t)(c >> 64);
+    c = (u128)a.v[1] * a.v[2] + t[3];
+    t[3] = (uint64_t)c;
+    c >>= 64;
+    c += (u128)a.v[1] * a.v[3] + t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    c = (u128)a.v[2] * a.v[3] + t[5];
+    t[5] = (uint64_t)c;
+    t[6] = (uint64_t)(c >> 64);
+    // ... doubled ...
+    t[7] = t[6] >> 63;
+    for (int i = 6; i > 1; i--) t[i] = (t[i] << 1) | (t[i - 1] >> 63);
+    t[1] <<= 1;
+    // ... plus the four squares
+    c = 0;
+    for (int i = 0; i < 4; i++) {
+      const u128 sq = (u128)a.v[i] * a.v[i];
+      c += (u128)t[2 * i] + (uint64_t)sq;
+      t[2 * i] = (uint64_t)c;
+      c >>= 64;
+      c += (u128)t[2 * i + 1] + (uint64_t)(sq >> 64);
+      t[2 * i + 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    return reduce512(t);
+  }
+  static HFe import(const HFe& mont) { return h_from_mont<Secp256k1Fq>(mont); }
+  static HFe to_mont(const HFe& v) {
+    const HFe r2{{Secp256k1Fq::r264(0), Secp256k1Fq::r264(1), Secp256k1Fq::r264(2), Secp256k1Fq::r264(3)}};
+    return h_mul<Secp256k1Fq>(v, r2);
+  }
+};
+
+struct HJac {
+  HFe x, y, z;  // z = 0: identity
+};
+
+// dbl-2009-l (a = 0): 2M + 5S
+template <class O>
+inline HJac hj_dbl(const HJac& p) {
+  typedef typename O::Field F;
+  HFe a = O::sqr(p.x), b = O::sqr(p.y), c = O::sqr(b);
+  HFe t = h_sub<F>(h_sub<F>(O::sqr(h_add<F>(p.x, b)), a), c);
+  HFe d = h_dbl<F>(t);
+  HFe e = h_add<F>(h_dbl<F>(a), a);
+  HFe f = O::sqr(e);
+  HJac r;
+  r.x = h_sub<F>(f, h_dbl<F>(d));
+  HFe c8 = h_dbl<F>(h_dbl<F>(h_dbl<F>(c)));
+  r.y = h_sub<F>(O::mul(e, h_sub<F>(d, r.x)), c8);
+  r.z = h_dbl<F>(O::mul(p.y, p.z));  // 0 stays 0: the identity doubles to itself
+  return r;
+}
+
+template <class O>
+inline HJac hj_add(const HJac& p, const HJac& q) {
+  typedef typename O::Field F;
+  if (h_is_zero(q.z)) return p;
+  if (h_is_zero(p.z)) return q;
+  HFe z1z1 = O::sqr(p.z), z2z2 = O::sqr(q.z);
+  HFe u1 = O::mul(p.x, z2z2), u2 = O::mul(q.x, z1z1);
+  HFe s1 = O::mul(O::mul(p.y, q.z), z2z2), s2 = O::mul(O::mul(q.y, p.z), z1z1);
+  HFe h = h_sub<F>(u2, u1), r = h_sub<F>(s2, s1);
+  if (h_is_zero(h)) {
+    if (h_is_zero(r)) return hj_dbl<O>(p);
+    return HJac{p.x, p.y, h_zero()};
+  }
+  HFe hh = O::sqr(h), hhh = O::mul(h, hh), v = O::mul(u1, hh);
+  HJac o;
+  o.x = h_sub<F>(h_sub<F>(O::sqr(r), hhh), h_dbl<F>(v));
+  o.y = h_sub<F>(O::mul(r, h_sub<F>(v, o.x)), O::mul(s1, hhh));
+  o.z = O::mul(O::mul(p.z, q.z), h);
+  return o;
+}
+
+// XYZZ (x, y, zz = z^2, zzz = z^3, Montgomery form) -> the Jacobian representative with Z = z^3:
+// scaled by lambda = z^2 the point reads (x zz^2, y zz^3, zzz), all from known values
+template <class O>
+inline HJac hj_from_xyzz(const uint64_t* w) {
+  HFe x, y, zz, zzz;
+  memcpy(x.v, w, 32);
+  memcpy(y.v, w + 4, 32);
+  memcpy(zz.v, w + 8, 32);
+  memcpy(zzz.v, w + 12, 32);
+  if (h_is_zero(zz)) return HJac{h_zero(), h_zero(), h_zero()};
+  x = O::import(x);
+  y = O::import(y);
+  zz = O::import(zz);
+  zzz = O::import(zzz);
+  HFe t = O::sqr(zz);
+  return HJac{O::mul(x, t), O::mul(O::mul(y, t), zz), zzz};
+}
+
+// sum_w 2^(c*w) * win[w] -> normalised Jacobian (x, y, 1) or (1, 1, 0) in Montgomery form
+template <class O>
+inline void hj_combine_windows(const uint64_t* win, int n_windows, int c, uint64_t out[12]) {
+  typedef typename O::Field F;
+  HJac acc{h_zero(), h_zero(), h_zero()};
+  for (int w = n_windows - 1; w >= 0; w--) {
+    if (!h_is_zero(acc.z))
+      for (int k = 0; k < c; k++) acc = hj_dbl<O>(acc);
+    acc = hj_add<O>(acc, hj_from_xyzz<O>(win + (size_t)w * 16));
+  }
+  const HFe one = h_one<F>();
+  if (h_is_zero(acc.z)) {
+    memcpy(out, one.v, 32);
+    memcpy(out + 4, one.v, 32);
+    memset(out + 8, 0, 32);
+    return;
+  }
+  const HFe X = O::to_mont(acc.x), Y = O::to_mont(acc.y), Z = O::to_mont(acc.z);
+  const HFe zi = h_inv_kaliski<F>(Z);
+  const HFe zi2 = h_sqr<F>(zi);
+  const HFe x = h_mul<F>(X, zi2), y = h_mul<F>(Y, h_mul<F>(zi2, zi));
+  memcpy(out, x.v, 32);
+  memcpy(out + 4, y.v, 32);
+  memcpy(out + 8, one.v, 32);
 }
 
 }  // namespace host

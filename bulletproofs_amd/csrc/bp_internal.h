@@ -60,6 +60,11 @@ hipError_t launch_ipa_round_fold(int curve, u32* a, u32* b, u32* cg, u32* ch, si
 constexpr size_t kIpaPrepMaxHalf = 16384;
 hipError_t launch_ipa_round_prep(int curve, const u32* a, const u32* b, const u32* cg, const u32* ch, size_t n0,
                                  size_t half, FeArg factor, int scale, u32* eg, u32* eh, u32* dots, hipStream_t st);
+// bp_ipa_round_fold and the launch_ipa_round_prep of the next round in one launch; (a, b) are folded
+// out of place into (a2, b2), half = length of the folded vectors >= 2, half / 2 <= kIpaPrepMaxHalf
+hipError_t launch_ipa_fold_prep(int curve, const u32* a, const u32* b, u32* a2, u32* b2, u32* cg, u32* ch, size_t n0,
+                                size_t half, FeArg x, FeArg x_inv, FeArg factor, int scale, u32* eg, u32* eh, u32* dots,
+                                hipStream_t st);
 hipError_t launch_ipa_scalars(int curve, const u32* a, const u32* b, const u32* cg, const u32* ch, size_t n0,
                               size_t half, u32* eg, u32* eh, hipStream_t st);
 hipError_t launch_fill_one(int curve, u32* v, size_t n, hipStream_t st);
@@ -141,6 +146,12 @@ struct MsmPlan {
   bool small;     // one-launch front end (digits, counting sort, bounds) per window, tree accumulation
   bool mid;       // sliced counting sort (three launches), tree accumulation
   bool tab;       // points come from window tables: all digit windows share one bucket set per group
+  // table plan small enough for the one-launch front end: the digit windows keep their own bucket
+  // sets (the launches are those of the plan without tables, only the points read differ) and the
+  // window sums, which the tables have already multiplied by their powers of two, are added up
+  // without doublings
+  bool tab_virtual;
+  int finish_c;   // doublings between consecutive window sums when they are combined: c, or 0 (tab_virtual)
   int digit_windows;  // windows of the digit decomposition (= group_windows unless tab)
   int stages;     // > 1: the windows are processed in this many consecutive batches on three streams
   bool two_level; // chunked path: two-level counting sort in place of the key-value radix sort

@@ -23,6 +23,7 @@
 
 #include "bp_curve.h"
 #include "bp_internal.h"
+#include "bp_quad.h"
 
 namespace bp {
 
@@ -111,10 +112,13 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   const int value_bits = curve == BP_VESTA ? 254 : 255;
   p.group_windows = (value_bits + 1 + p.c - 1) / p.c;
   p.digit_windows = p.group_windows;
+  p.tab_virtual = p.tab && small_ok && p.digit_windows * groups <= 64 && !getenv("BP_MSM_TAB_MERGED");
+  p.finish_c = p.tab_virtual ? 0 : p.c;
   if (p.tab) {
-    // every digit window lands in the one bucket set of its group: one output "window" per group
     if (p.digit_windows > kTableWindows) return hipErrorInvalidValue;
-    p.group_windows = 1;
+    // every digit window lands in the one bucket set of its group: one output "window" per group
+    // (unless the plan keeps them apart, see tab_virtual)
+    if (!p.tab_virtual) p.group_windows = 1;
   }
   p.n_windows = p.group_windows * groups;
   p.n_buckets = 1u << (p.c - 1);
@@ -197,14 +201,14 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   // number of partial sums per bucket small
   if ((p.entries >> 21) > p.chunk) p.chunk = (u32)((p.entries >> 21) > 4096 ? 4096 : (p.entries >> 21));
   p.nc_cap = p.entries / p.chunk + nbt + 1 + kMsmMaxStages;  // room for one rounding slot per batch
-  p.small = small_ok && p.n_buckets <= kSmallMaxBuckets && !p.tab;
+  p.small = small_ok && p.n_buckets <= kSmallMaxBuckets && (!p.tab || p.tab_virtual);
   // narrow windows on more points than one block sorts: the sliced counting sort
-  p.mid = p.tab || (!p.small && n_total > 0 && p.n_buckets >= 64 && p.n_buckets <= kMidMaxBuckets &&
+  p.mid = (p.tab && !p.tab_virtual) || (!p.small && n_total > 0 && p.n_buckets >= 64 && p.n_buckets <= kMidMaxBuckets &&
                     n_total <= ((size_t)1 << 20) && !getenv("BP_MSM_NO_MID"));
   if (p.small || p.mid) {
     // every output window owns a fixed range of slots of the sorted-entry array: n_total, or
     // all of a group's digit windows together for table plans
-    size_t need = (size_t)p.n_windows * (p.tab ? p.entries : n_total) * sizeof(u32);
+    size_t need = (size_t)p.n_windows * (p.tab && !p.tab_virtual ? p.entries : n_total) * sizeof(u32);
     if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
   }
   if (p.mid) {
@@ -400,7 +404,9 @@ __global__ __launch_bounds__(1024) void k_small_front(
     const uint8_t* __restrict__ inf1, size_t n1, const u32* __restrict__ x0, const u32* __restrict__ y0,
     const u32* __restrict__ x1, const u32* __restrict__ y1, u32* __restrict__ packed, DigitGroups sel, int c,
     int group_windows, u32 n_buckets, int wshift, u32* __restrict__ sorted_vals, u32* __restrict__ bucket_start,
-    u32* __restrict__ bucket_end, u32* __restrict__ heavy_count) {
+    u32* __restrict__ bucket_end, u32* __restrict__ heavy_count, u32 tab_stride, u32 tab_off0, u32 tab_off1) {
+  // tab_stride != 0: the points are records of a base set's window tables (record of window w and
+  // base j at w * tab_stride + j); nothing is packed and an entry names its table record
   using Fr = typename C::Fr;
   __shared__ u32 hist[kSmallMaxBuckets];
   __shared__ u32 off[kSmallMaxBuckets];
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(1024) void k_small_front(
   // Packing: every point's x|y record is written (in the pipeline's form) by exactly one lane of
   // the grid, ahead of the digit loop so that the conversion does not share registers with it.
 #pragma unroll 1
-  for (size_t i = (size_t)threadIdx.x * gridDim.x + wid; i < n; i += (size_t)kSmallThreads * gridDim.x) {
+  for (size_t i = (size_t)threadIdx.x * gridDim.x + wid; i < n && tab_stride == 0; i += (size_t)kSmallThreads * gridDim.x) {
     const bool second = i >= n0;
     const u32* px = second ? x1 + (i - n0) * 8 : x0 + i * 8;
     const u32* py = second ? y1 + (i - n0) * 8 : y0 + i * 8;
@@ -509,6 +515,10 @@ __global__ __launch_bounds__(1024) void k_small_front(
       raw = (u32)(two >> sh) & mask;
     }
     u32 v = raw + carry, key, val = (u32)i | (wid << wshift);
+    if (tab_stride) {
+      const u32 j = is_extra ? sel.extra_tab[i - n01] : second ? tab_off1 + (u32)(i - n0) : tab_off0 + (u32)i;
+      val = (w * tab_stride + j) | (wid << wshift);
+    }
     if (v > half) {
       u32 mag = (1u << c) - v;
       key = mag ? mag - 1 : invalid;
@@ -1430,6 +1440,63 @@ constexpr u32 kTreeHeavyBlocks = 128;
 constexpr u32 kTreeHeavyMax = 8192;
 constexpr u32 kTreeHeavyList = 128;  // buckets a block looks at with the default windows: <= 58 * 256 / 128
 
+// A crowded bucket (more than heavy_from entries, up to heavy_max) taken by a whole 256-lane block:
+// block h of the first kTreeHeavyBlocks looks at buckets h, h + kTreeHeavyBlocks, ...
+template <class C>
+BP_DEV void tree_heavy_block(const u32* __restrict__ packed, const u32* __restrict__ vals,
+                             const u32* __restrict__ start, const u32* __restrict__ end, size_t nbt, u32 heavy_from,
+                             u32 heavy_max, u32 idx_mask, u32* __restrict__ buckets, u32* __restrict__ heavy,
+                             u32* __restrict__ heavy_count) {
+  using F = typename C::Fq;
+  __shared__ u32 list[kTreeHeavyList];
+  __shared__ u32 n_list;
+  __shared__ u32 wave_sum[4 * 32];
+  if (threadIdx.x == 0) n_list = 0;
+  __syncthreads();
+  for (size_t b = blockIdx.x + (size_t)kTreeHeavyBlocks * threadIdx.x; b < nbt;
+       b += (size_t)kTreeHeavyBlocks * blockDim.x) {
+    const u32 cnt = end[b] - start[b];
+    if (cnt > heavy_from && cnt <= heavy_max) {
+      const u32 slot = atomicAdd(&n_list, 1u);
+      if (slot < kTreeHeavyList)
+        list[slot] = (u32)b;
+      else  // more than the list holds (very wide windows): leave it to the queue
+        heavy[atomicAdd(heavy_count, 1u)] = (u32)b;
+    }
+  }
+  __syncthreads();
+  const u32 count = n_list < kTreeHeavyList ? n_list : kTreeHeavyList;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (u32 q = 0; q < count; q++) {
+    const u32 b = list[q];
+    const u32 s = start[b], e = end[b];
+    Xyzz acc = xyzz_identity<F>();
+    for (u32 p = s + threadIdx.x; p < e; p += blockDim.x) {
+      u32 v = vals[p];
+      size_t idx = v & idx_mask;
+      Fe qx = fe_load(packed + idx * 16);
+      Fe qy = fe_load(packed + idx * 16 + 8);
+      if (v >> 31) qy = fe_neg<F>(qy);
+      xyzz_madd<F>(acc, qx, qy);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      Xyzz o = xyzz_shfl_down(acc, off, 64);
+      if (lane < off) xyzz_add<F>(acc, o);
+    }
+    if (lane == 0) xyzz_store_aos(wave_sum + wave * 32, acc);
+    __syncthreads();
+    if (wave == 0) {
+      acc = lane < 4 ? xyzz_load_aos(wave_sum + lane * 32) : xyzz_identity<F>();
+      for (int off = 2; off > 0; off >>= 1) {
+        Xyzz o = xyzz_shfl_down(acc, off, 64);
+        if (lane < off) xyzz_add<F>(acc, o);
+      }
+      if (lane == 0) xyzz_store_soa(buckets, nbt, b, acc);
+    }
+    __syncthreads();
+  }
+}
+
 template <class C>
 __global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ packed, const u32* __restrict__ vals,
                                                      const u32* __restrict__ start, const u32* __restrict__ end,
@@ -1438,53 +1505,7 @@ __global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ pac
                                                      u32* __restrict__ heavy, u32* __restrict__ heavy_count) {
   using F = typename C::Fq;
   if (blockIdx.x < kTreeHeavyBlocks) {
-    __shared__ u32 list[kTreeHeavyList];
-    __shared__ u32 n_list;
-    __shared__ u32 wave_sum[4 * 32];
-    if (threadIdx.x == 0) n_list = 0;
-    __syncthreads();
-    for (size_t b = blockIdx.x + (size_t)kTreeHeavyBlocks * threadIdx.x; b < nbt;
-         b += (size_t)kTreeHeavyBlocks * blockDim.x) {
-      const u32 cnt = end[b] - start[b];
-      if (cnt > heavy_from && cnt <= heavy_max) {
-        const u32 slot = atomicAdd(&n_list, 1u);
-        if (slot < kTreeHeavyList)
-          list[slot] = (u32)b;
-        else  // more than the list holds (very wide windows): leave it to the queue
-          heavy[atomicAdd(heavy_count, 1u)] = (u32)b;
-      }
-    }
-    __syncthreads();
-    const u32 count = n_list < kTreeHeavyList ? n_list : kTreeHeavyList;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (u32 q = 0; q < count; q++) {
-      const u32 b = list[q];
-      const u32 s = start[b], e = end[b];
-      Xyzz acc = xyzz_identity<F>();
-      for (u32 p = s + threadIdx.x; p < e; p += blockDim.x) {
-        u32 v = vals[p];
-        size_t idx = v & idx_mask;
-        Fe qx = fe_load(packed + idx * 16);
-        Fe qy = fe_load(packed + idx * 16 + 8);
-        if (v >> 31) qy = fe_neg<F>(qy);
-        xyzz_madd<F>(acc, qx, qy);
-      }
-      for (int off = 32; off > 0; off >>= 1) {
-        Xyzz o = xyzz_shfl_down(acc, off, 64);
-        if (lane < off) xyzz_add<F>(acc, o);
-      }
-      if (lane == 0) xyzz_store_aos(wave_sum + wave * 32, acc);
-      __syncthreads();
-      if (wave == 0) {
-        acc = lane < 4 ? xyzz_load_aos(wave_sum + lane * 32) : xyzz_identity<F>();
-        for (int off = 2; off > 0; off >>= 1) {
-          Xyzz o = xyzz_shfl_down(acc, off, 64);
-          if (lane < off) xyzz_add<F>(acc, o);
-        }
-        if (lane == 0) xyzz_store_soa(buckets, nbt, b, acc);
-      }
-      __syncthreads();
-    }
+    tree_heavy_block<C>(packed, vals, start, end, nbt, heavy_from, heavy_max, idx_mask, buckets, heavy, heavy_count);
     return;
   }
   size_t t = (size_t)(blockIdx.x - kTreeHeavyBlocks) * blockDim.x + threadIdx.x;
@@ -1515,6 +1536,78 @@ __global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ pac
     if ((int)sub < off) xyzz_add<F>(acc, o);
   }
   if (live && !is_heavy && sub == 0) xyzz_store_soa(buckets, nbt, b, acc);
+}
+
+// k_bucket_tree with every addition spread over four lanes (bp_quad.h): 2^log_q quads per bucket,
+// each adds its share of the bucket's entries (strided) into a point it keeps in LDS, then a tree
+// over the quads of the bucket.  What counts in the launches this serves (a few thousand entries
+// per window: the rounds of an inner-product argument) is the length of the dependent chain, and
+// a quad addition takes about half the time of a one-lane addition.  64 quads per block.
+constexpr int kBucketQuadThreads = 256;
+
+template <class C>
+__global__ __launch_bounds__(kBucketQuadThreads) void k_bucket_quad(
+    const u32* __restrict__ packed, const u32* __restrict__ vals, const u32* __restrict__ start,
+    const u32* __restrict__ end, size_t nbt, int log_q, u32 heavy_from, u32 heavy_max, u32 idx_mask,
+    u32* __restrict__ buckets, u32* __restrict__ heavy, u32* __restrict__ heavy_count) {
+  using F = typename C::Fq;
+  if (blockIdx.x < kTreeHeavyBlocks) {
+    tree_heavy_block<C>(packed, vals, start, end, nbt, heavy_from, heavy_max, idx_mask, buckets, heavy, heavy_count);
+    return;
+  }
+  constexpr int kQuads = kBucketQuadThreads / 4;
+  __shared__ u32 pts[kQuads * 2 * 32];  // per quad: its running sum, the entry being added
+  __shared__ u32 scr_all[kQuads * kQuadScratch * 8];
+  __shared__ u32 zero[8];
+  const u32 tid = threadIdx.x, quad = tid >> 2;
+  const int role = (int)(tid & 3u), coord = quad_coord(role);
+  u32* scr = scr_all + quad * (kQuadScratch * 8);
+  u32* acc = pts + quad * 64;
+  if (tid < 8) zero[tid] = 0;
+  const Fe one = fe_one<F>();
+  const u32 per_block = (u32)kQuads >> log_q;
+  const size_t b = (size_t)(blockIdx.x - kTreeHeavyBlocks) * per_block + (quad >> log_q);
+  const u32 sub = quad & ((1u << log_q) - 1u), n_sub = 1u << log_q;
+  const bool live = b < nbt;
+  u32 s = 0, e = 0;
+  if (live) {
+    s = start[b];
+    e = end[b];
+  }
+  const bool is_heavy = e - s > heavy_from;
+  if (is_heavy) {
+    if (sub == 0 && role == 0 && e - s > heavy_max) heavy[atomicAdd(heavy_count, 1u)] = (u32)b;
+    e = s;
+  }
+  fe_store(acc + role * 8, quad_identity_coord(role, one));
+  __syncthreads();  // zero[] and the identities
+  for (u32 p = s + sub; p < e; p += n_sub) {
+    const u32 v = vals[p];
+    const size_t idx = v & idx_mask;
+    // the entry as an XYZZ point behind the sum: x, y (negated for a negative digit), 1, 1
+    Fe val = one;
+    if (role < 2) val = fe_load(packed + idx * 16 + role * 8);
+    if (role == 1 && (v >> 31)) val = fe_neg<F>(val);
+    fe_store(acc + 32 + role * 8, val);
+    quad_sync();
+    Fe out;
+    const bool changed = quad_add<F>(pts, scr, zero, quad * 2, quad * 2 + 1, role, out);
+    quad_sync();
+    if (changed) fe_store(acc + coord * 8, out);
+    quad_sync();
+  }
+  for (int l = 0; l < log_q; l++) {
+    __syncthreads();
+    if ((sub & ((2u << l) - 1u)) == 0) {
+      Fe out;
+      const bool changed = quad_add<F>(pts, scr, zero, quad * 2, (quad + (1u << l)) * 2, role, out);
+      quad_sync();
+      if (changed) fe_store(acc + coord * 8, out);
+      quad_sync();
+    }
+  }
+  if (live && !is_heavy && sub == 0)
+    fe_store(buckets + ((size_t)role * nbt + b) * 8, fe_load(acc + role * 8));
 }
 
 // one 1024-lane block per queued bucket: strided mixed additions, shuffle tree per wave,
@@ -1919,16 +2012,17 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     if (p1.sel_half && p1.n % (2 * p1.sel_half)) return hipErrorInvalidValue;
     if (!p0.sel_half && !p1.sel_half && p0.n && p1.n && p0.group_lo > p1.group_lo) return hipErrorInvalidValue;
   }
+  if (plan.tab && (!table || !table->rec)) return hipErrorInvalidValue;
   if (plan.small) {
     // sorted entries and bucket bounds straight into the buffers the accumulation reads
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_small_front<C>, dim3((unsigned)plan.n_windows), dim3(kSmallThreads), 0, st,
                                              p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x, p0.y, p1.x, p1.y, ws.packed,
                                              sel, plan.c, plan.group_windows, plan.n_buckets, plan.wshift, ws.vals_b,
-                                             ws.bucket_start, ws.bucket_end, ws.heavy_count));
+                                             ws.bucket_start, ws.bucket_end, ws.heavy_count,
+                                             plan.tab ? (u32)table->stride : 0u, (u32)p0.tab_offset, (u32)p1.tab_offset));
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1);
+    return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1, plan.tab ? table->rec : nullptr);
   }
-  if (plan.tab && (!table || !table->rec)) return hipErrorInvalidValue;
   if (plan.mid) {
     const u32 n_slices = (u32)((n + kMidSlice - 1) / kMidSlice);
     const int tab = plan.tab ? 1 : 0;
@@ -2118,7 +2212,30 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
     const bool no_queue = !plan.tab && plan.n_total <= kTreeHeavyMax + kTreeHeavyMax / 8 &&
                           nbt <= (size_t)kTreeHeavyBlocks * kTreeHeavyList;
     const u32 heavy_max = no_queue && plan.n_total > kTreeHeavyMax ? (u32)plan.n_total : kTreeHeavyMax;
-    if (nbt <= 512 && per_bucket >= 512) {
+    // Four lanes per addition (k_bucket_quad) where few buckets hold many entries each (table plans
+    // whose digit windows share a bucket set): there the chain of dependent additions sets the time.
+    // With a few dozen entries per bucket the launch is bound by its total work and the one-lane tree
+    // wins (IPA round of 2 * 4096 points: 60 us against 78 us).  BP_MSM_TREE_QUAD=1/0 forces a choice.
+    static const char* quad_env = getenv("BP_MSM_TREE_QUAD");
+    const bool quad_tree = quad_env ? atoi(quad_env) != 0 : (nbt <= 512 && per_bucket >= 512);
+    if (quad_tree) {
+      // quads per bucket: about four entries each, at most the 64 of a block
+      int log_q = 0;
+      while (log_q < 6 && ((size_t)4 << log_q) < per_bucket) log_q++;
+      const size_t n_quads = (size_t)1 << log_q;
+      size_t per_quad = 2 * ((per_bucket + n_quads - 1) / n_quads);
+      if (per_quad < 16) per_quad = 16;
+      const u32 q_heavy_from = (u32)(per_quad * n_quads);
+      const size_t per_block = (size_t)(kBucketQuadThreads / 4) >> log_q;
+      DISPATCH_CURVE(curve, {
+        hipLaunchKernelGGL(k_bucket_quad<C>, dim3((unsigned)((nbt + per_block - 1) / per_block) + kTreeHeavyBlocks),
+                           dim3(kBucketQuadThreads), 0, st, points, ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, log_q,
+                           q_heavy_from, heavy_max, idx_mask, ws.buckets, ws.heavy, ws.heavy_count);
+        if (!no_queue)
+          hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3(256), dim3(1024), 0, st, points, ws.vals_b,
+                             ws.bucket_start, ws.bucket_end, nbt, idx_mask, ws.buckets, ws.heavy, ws.heavy_count);
+      });
+    } else if (nbt <= 512 && per_bucket >= 512) {
       // few buckets with many entries each (table plans on small inputs): a block per bucket
       DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3((unsigned)nbt), dim3(1024), 0, st, points,
                                                ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, idx_mask, ws.buckets,

@@ -35,11 +35,11 @@ __global__ __launch_bounds__(256) void k_fold_scalars(const u32* __restrict__ l,
                                                       FeArg ya, u32* __restrict__ out) {
   const Fe x = arg_to_fe(xa), y = arg_to_fe(ya);
   size_t stride = (size_t)gridDim.x * blockDim.x;
+  // both products of an output are summed before the one reduction (fe_mul2)
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < h; i += stride) {
-    Fe a = fe_load(l + i * 8);
-    Fe b = fe_load(r + i * 8);
-    Fe o = fe_add<F>(fe_mul<F>(a, x), fe_mul<F>(b, y));
-    fe_store(out + i * 8, o);
+    Fe a = fe_load_nt(l + i * 8);
+    Fe b = fe_load_nt(r + i * 8);
+    fe_store_nt(out + i * 8, fe_mul2<F>(a, x, b, y));
   }
 }
 
@@ -98,14 +98,17 @@ __global__ __launch_bounds__(256) void k_dot_partial(const u32* __restrict__ a,
   Fe acc = fe_zero();
   size_t stride = (size_t)gridDim.x * blockDim.x;
   if (b) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-      Fe x = fe_load(a + i * 8);
-      Fe y = fe_load(b + i * 8);
-      acc = fe_add<F>(acc, fe_mul<F>(x, y));
+    // two terms per step, summed before the one reduction (fe_mul2)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < n; i += 2 * stride) {
+      Fe x0 = fe_load_nt(a + i * 8), y0 = fe_load_nt(b + i * 8);
+      Fe x1 = fe_load_nt(a + (i + stride) * 8), y1 = fe_load_nt(b + (i + stride) * 8);
+      acc = fe_add<F>(acc, fe_mul2<F>(x0, y0, x1, y1));
     }
+    if (i < n) acc = fe_add<F>(acc, fe_mul<F>(fe_load_nt(a + i * 8), fe_load_nt(b + i * 8)));
   } else {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-      acc = fe_add<F>(acc, fe_load(a + i * 8));
+      acc = fe_add<F>(acc, fe_load_nt(a + i * 8));
   }
   Fe tot = block_reduce_add<F>(acc, lds);
   if (threadIdx.x == 0) fe_store(partials + (size_t)blockIdx.x * 8, tot);
@@ -217,6 +220,18 @@ template <class F>
 __global__ __launch_bounds__(256) void k_svec_expand(const u32* __restrict__ table, int k, int lo,
                                                      u32* __restrict__ out) {
   size_t n = (size_t)1 << k, n_lo = (size_t)1 << lo;
+  if (n_lo == blockDim.x) {
+    // a lane keeps its low-bit product; the high-bit product is the same for the whole block
+    // (a uniform address: it arrives through the scalar unit), so an output costs one
+    // multiplication and one 32-byte store, and a block writes 8 KiB runs
+    const Fe a = fe_load(table + (size_t)threadIdx.x * 8);
+    const size_t n_hi = n >> lo;
+    for (size_t hi = blockIdx.x; hi < n_hi; hi += gridDim.x) {
+      const Fe b = fe_load(table + (n_lo + hi) * 8);
+      fe_store_nt(out + ((hi << lo) + threadIdx.x) * 8, fe_mul<F>(a, b));
+    }
+    return;
+  }
   size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     Fe a = fe_load(table + (i & (n_lo - 1)) * 8);
@@ -598,6 +613,71 @@ __global__ __launch_bounds__(1024) void k_ipa_round_prep(const u32* __restrict__
   if (ch) fe_store(eh + k * 8, fe_mul<F>(fe_load(ch + k * 8), fe_load(b + other * 8)));
 }
 
+// A fold and the preparation of the round that follows it in one launch (the two are separated
+// only by the caller's challenge, which arrives before either).  The vectors are folded out of
+// place, (a, b) of length 2*half into (a2, b2) of length half, so that every block can recompute
+// the folded elements it needs from the unfolded vectors while block 0 writes them:
+//   a2[i] = a[i]*x + a[i+half]*x^-1,  b2[i] = b[i]*x^-1 + b[i+half]*x        (k_ipa_round_fold)
+// Block 0 also leaves the next round's c_l = <a2_lo, b2_hi>, c_r = <a2_hi, b2_lo> in dots (and the
+// scaled pair); the other blocks update the generator coefficients and write the next round's MSM
+// scalars eg[k] = cg[k] * a2[other], eh[k] = ch[k] * b2[other] (k_ipa_round_prep).  half >= 2.
+template <class F>
+__global__ __launch_bounds__(1024) void k_ipa_fold_prep(const u32* __restrict__ a, const u32* __restrict__ b,
+                                                        u32* __restrict__ a2, u32* __restrict__ b2,
+                                                        u32* __restrict__ cg, u32* __restrict__ ch, size_t n0,
+                                                        size_t half, FeArg xa, FeArg xia, FeArg factor, int scale,
+                                                        u32* __restrict__ eg, u32* __restrict__ eh,
+                                                        u32* __restrict__ dots) {
+  const Fe x = arg_to_fe(xa), xi = arg_to_fe(xia);
+  const size_t q = half / 2;  // half of the next round
+  if (blockIdx.x == 0) {
+    __shared__ u32 lds[2 * 16 * 8];
+    Fe accl = fe_zero(), accr = fe_zero();
+    for (size_t i = threadIdx.x; i < q; i += blockDim.x) {
+      Fe al = fe_mul2<F>(fe_load(a + i * 8), x, fe_load(a + (i + half) * 8), xi);
+      Fe ah = fe_mul2<F>(fe_load(a + (i + q) * 8), x, fe_load(a + (i + q + half) * 8), xi);
+      Fe bl = fe_mul2<F>(fe_load(b + i * 8), xi, fe_load(b + (i + half) * 8), x);
+      Fe bh = fe_mul2<F>(fe_load(b + (i + q) * 8), xi, fe_load(b + (i + q + half) * 8), x);
+      fe_store(a2 + i * 8, al);
+      fe_store(a2 + (i + q) * 8, ah);
+      fe_store(b2 + i * 8, bl);
+      fe_store(b2 + (i + q) * 8, bh);
+      accl = fe_add<F>(accl, fe_mul<F>(al, bh));
+      accr = fe_add<F>(accr, fe_mul<F>(ah, bl));
+    }
+    Fe tl = block_reduce_add<F>(accl, lds);
+    Fe tr = block_reduce_add<F>(accr, lds + 16 * 8);
+    if (threadIdx.x == 0) {
+      fe_store(dots, tl);
+      fe_store(dots + 8, tr);
+      if (scale) {
+        const Fe f = arg_to_fe(factor);
+        fe_store(dots + 16, fe_mul<F>(tl, f));
+        fe_store(dots + 24, fe_mul<F>(tr, f));
+      }
+    }
+    return;
+  }
+  size_t k = (size_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x;
+  if (k >= n0) return;
+  // the fold's coefficient update, then the next round's pairing
+  const bool upper = (k & (2 * half - 1)) >= half;
+  const size_t i = k & (half - 1);
+  const size_t other = i >= q ? i - q : i + q;
+  {
+    Fe c = fe_mul<F>(fe_load(cg + k * 8), upper ? x : xi);
+    fe_store(cg + k * 8, c);
+    Fe av = fe_mul2<F>(fe_load(a + other * 8), x, fe_load(a + (other + half) * 8), xi);
+    fe_store(eg + k * 8, fe_mul<F>(c, av));
+  }
+  if (ch) {
+    Fe c = fe_mul<F>(fe_load(ch + k * 8), upper ? xi : x);
+    fe_store(ch + k * 8, c);
+    Fe bv = fe_mul2<F>(fe_load(b + other * 8), xi, fe_load(b + (other + half) * 8), x);
+    fe_store(eh + k * 8, fe_mul<F>(c, bv));
+  }
+}
+
 template <class F>
 __global__ __launch_bounds__(256) void k_fill_one(u32* __restrict__ v, size_t n) {
   size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -633,6 +713,16 @@ hipError_t launch_ipa_round_prep(int curve, const u32* a, const u32* b, const u3
   unsigned blocks = 1 + (unsigned)((n0 + 1023) / 1024);
   DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipa_round_prep<F>, dim3(blocks), dim3(1024), 0, st, a, b, cg, ch, n0, half,
                                         factor, scale, eg, eh, dots));
+  return hipGetLastError();
+}
+
+hipError_t launch_ipa_fold_prep(int curve, const u32* a, const u32* b, u32* a2, u32* b2, u32* cg, u32* ch, size_t n0,
+                                size_t half, FeArg x, FeArg x_inv, FeArg factor, int scale, u32* eg, u32* eh, u32* dots,
+                                hipStream_t st) {
+  if (half < 2 || half / 2 > kIpaPrepMaxHalf) return hipErrorInvalidValue;
+  unsigned blocks = 1 + (unsigned)((n0 + 1023) / 1024);
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipa_fold_prep<F>, dim3(blocks), dim3(1024), 0, st, a, b, a2, b2, cg, ch, n0, half,
+                                        x, x_inv, factor, scale, eg, eh, dots));
   return hipGetLastError();
 }
 

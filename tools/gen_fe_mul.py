@@ -84,9 +84,12 @@ def ones_run_start(pl):
     return s if 8 - s >= 3 and s >= 1 else 8
 
 
-def gen_field(name, p, redc=False):
+def gen_field(name, p, redc=False, dual=False):
     """redc=True: the Montgomery reduction alone, a * 2^-256 mod p (the multiply with b = 1: a's
-    limbs enter their columns directly, the 64 partial products are not issued)"""
+    limbs enter their columns directly, the 64 partial products are not issued).
+    dual=True: (a*b + c*d) * 2^-256 mod p with ONE reduction: both products are summed column by
+    column before the multiples of p are added (the shape of fold_scalars and of the terms of an
+    inner product); the value before the final subtractions is below 3p"""
     pl = limbs(p)
     inv = (-pow(p, -1, 1 << 32)) % (1 << 32)
     run = ones_run_start(pl)
@@ -95,6 +98,8 @@ def gen_field(name, p, redc=False):
     out.append("// %s: p = 0x%064x" % (name, p))
     if redc:
         out.append("__device__ __forceinline__ Fe fe_redc_dev_%s(const Fe& a) {" % name)
+    elif dual:
+        out.append("__device__ __forceinline__ Fe fe_mul2_dev_%s(const Fe& a, const Fe& b, const Fe& c, const Fe& d) {" % name)
     else:
         out.append("__device__ __forceinline__ Fe fe_mul_dev_%s(const Fe& a, const Fe& b) {" % name)
     out.append("  uint64_t acc = 0;")
@@ -115,6 +120,13 @@ def gen_field(name, p, redc=False):
                 if 0 <= j <= 7:
                     ab.mac(ab.operand("v", "a.v[%d]" % i), ab.operand("v", "b.v[%d]" % j))
         ab.emit(out)
+        if dual:
+            cd = Asm()
+            for i in range(8):
+                j = k - i
+                if 0 <= j <= 7:
+                    cd.mac(cd.operand("v", "c.v[%d]" % i), cd.operand("v", "d.v[%d]" % j))
+            cd.emit(out)
         mp = Asm()
         for i in range(8):
             j = k - i
@@ -142,7 +154,7 @@ def gen_field(name, p, redc=False):
     if signed:
         out.append("  acc += m7;  // column 15")
     out.append("  r.v[7] = (uint32_t)acc;")
-    out.append("  return fe_reduce_once<%s>(r, (uint32_t)(acc >> 32));" % name)
+    out.append("  return fe_reduce_%s<%s>(r, (uint32_t)(acc >> 32));" % ("twice" if dual else "once", name))
     out.append("}")
     return out
 
@@ -205,6 +217,9 @@ def main():
         out.append("")
         out += gen_field(name, p, redc=True)
         out.append("")
+        if name.endswith("Fr"):
+            out += gen_field(name, p, dual=True)
+            out.append("")
     out += gen_secp_plain()
     out.append("")
     out.append("template <class F>\n__device__ __forceinline__ Fe fe_mul_dev(const Fe& a, const Fe& b);")
@@ -213,6 +228,10 @@ def main():
     out.append("template <class F>\n__device__ __forceinline__ Fe fe_redc_dev(const Fe& a);")
     for name in FIELDS:
         out.append("template <>\n__device__ __forceinline__ Fe fe_redc_dev<%s>(const Fe& a) {\n  return fe_redc_dev_%s(a);\n}" % (name, name))
+    out.append("template <class F>\n__device__ __forceinline__ Fe fe_mul2_dev(const Fe& a, const Fe& b, const Fe& c, const Fe& d);")
+    for name in FIELDS:
+        if name.endswith("Fr"):
+            out.append("template <>\n__device__ __forceinline__ Fe fe_mul2_dev<%s>(const Fe& a, const Fe& b, const Fe& c, const Fe& d) {\n  return fe_mul2_dev_%s(a, b, c, d);\n}" % (name, name))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bulletproofs_amd", "csrc", "bp_field_mul_gen.h")
     open(path, "w").write("\n".join(out) + "\n")
     print("wrote", os.path.normpath(path))
