@@ -62,6 +62,48 @@ def best(fn, reps=5):
 peak = ctx.int_mad_peak(4000)
 print(json.dumps({"kernel": "v_mad_u64_u32 peak", "mac_per_s": peak}), flush=True)
 
+# ---- what this GPU's memory delivers to the simplest kernels (torch's own copy, fill and sum over
+# 512 MiB buffers, HIP-event timed): the rates the streaming kernels below are priced against ----
+def torch_rate(fn, nbytes, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best_ms = 1e30
+    for _ in range(reps):
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        best_ms = min(best_ms, e0.elapsed_time(e1))
+    return nbytes / best_ms / 1e6  # GB/s
+
+
+_src = torch.randint(0, 1 << 62, (1 << 26,), dtype=torch.int64, device="cuda")  # 512 MiB
+_dst = torch.empty_like(_src)
+calib = {"copy_GBps": torch_rate(lambda: _dst.copy_(_src), 2 * _src.numel() * 8),
+         "write_GBps": torch_rate(lambda: _dst.fill_(7), _src.numel() * 8),
+         "read_GBps": torch_rate(lambda: _src.sum(), _src.numel() * 8)}
+del _src, _dst
+print(json.dumps({"kernel": "memory calibration (torch copy_, fill_, sum over 512 MiB)", **calib}), flush=True)
+
+# ---- the scalar-field multiply in registers: the other ceiling of the streaming kernels ----
+import ctypes as _C  # noqa: E402
+
+
+def _mb(i, blocks, iters):
+    ms = _C.c_float()
+    ctx._chk(lib.bp_microbench(ctx.h, i, blocks, iters, _C.byref(ms)))
+    return ms.value
+
+
+_blocks, _it = 8192, 200
+fr_mul_rate = _blocks * 256 * _it * 2 / min(_mb(9, _blocks, _it) for _ in range(3)) * 1e3
+fr_mul2_rate = _blocks * 256 * _it * 2 / min(_mb(10, _blocks, _it) for _ in range(3)) * 1e3
+print(json.dumps({"kernel": "secp256k1 Fr multiply in registers (bp_microbench 9, 10)", "mul_per_s": fr_mul_rate,
+                  "dual_products_per_s": fr_mul2_rate,
+                  "s_vector_ceiling_GBps": fr_mul_rate * 32 / 1e9, "fold_scalars_ceiling_GBps": fr_mul2_rate * 96 / 1e9,
+                  "inner_product_ceiling_GBps": fr_mul2_rate * 128 / 1e9}), flush=True)
+
 # ---- streaming kernels ----
 for logn in (20, 24):
     n = 1 << logn
@@ -70,19 +112,21 @@ for logn in (20, 24):
     fn = lambda: ctx._chk(lib.bp_fold_scalars_dev(ctx.h, C, a.data_ptr(), b.data_ptr(), n, x.ctypes.data, y.ctypes.data, out.data_ptr()))  # noqa: E731
     mn, med = best(fn)
     print(json.dumps({"kernel": "fold_scalars", "n": n, "ms": mn, "GBps": 96 * n / mn / 1e6, "frac_hbm_8TBs": 96 * n / mn / 1e6 / 8000,
-                      "TMACps": 272 * n / mn / 1e9, "frac_int_peak": 272 * n / mn * 1e3 / peak}), flush=True)
+                      "frac_of_copy_rate": 96 * n / mn / 1e6 / calib["copy_GBps"],
+                      "frac_of_multiply_ceiling": n / mn * 1e3 / fr_mul2_rate, "TMACps": 272 * n / mn / 1e9, "frac_int_peak": 272 * n / mn * 1e3 / peak}), flush=True)
     res = np.zeros(4, dtype=np.uint64)
     fn = lambda: ctx._chk(lib.bp_inner_product_dev(ctx.h, C, a.data_ptr(), b.data_ptr(), n, res.ctypes.data))  # noqa: E731
     mn, med = best(fn)
     print(json.dumps({"kernel": "inner_product", "n": n, "ms": mn, "GBps": 64 * n / mn / 1e6, "frac_hbm_8TBs": 64 * n / mn / 1e6 / 8000,
-                      "TMACps": 136 * n / mn / 1e9, "frac_int_peak": 136 * n / mn * 1e3 / peak}), flush=True)
+                      "frac_of_read_rate": 64 * n / mn / 1e6 / calib["read_GBps"], "TMACps": 136 * n / mn / 1e9, "frac_int_peak": 136 * n / mn * 1e3 / peak}), flush=True)
     k = logn
     ch = rand_field(k)
     chi = ctx.batch_inversion(C, ch)
     fn = lambda: ctx._chk(lib.bp_s_vector_dev(ctx.h, C, ch.ctypes.data, chi.ctypes.data, k, out.data_ptr()))  # noqa: E731
     mn, med = best(fn)
     print(json.dumps({"kernel": "s_vector", "n": n, "ms": mn, "GBps": 32 * n / mn / 1e6, "frac_hbm_8TBs": 32 * n / mn / 1e6 / 8000,
-                      "TMACps": 136 * n / mn / 1e9}), flush=True)
+                      "frac_of_write_rate": 32 * n / mn / 1e6 / calib["write_GBps"],
+                      "frac_of_multiply_ceiling": n / mn * 1e3 / fr_mul_rate, "TMACps": 136 * n / mn / 1e9}), flush=True)
     del a, b, out
 
 # ---- curve kernels ----

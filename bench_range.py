@@ -6,6 +6,8 @@ import json
 import os
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import bulletproofs_amd as bp  # noqa: E402
@@ -31,4 +33,19 @@ for w in workers:
     thr = host_mirror.range_aggregate_throughput(0, bp.SECP256K1, gs, hs, ugh, values, gamma, n_bits, w, 8, SEED, SEED + 1)
     assert thr["ok"]
     out["concurrent"].append({"workers": w, "prove_per_s": thr["prove_per_s"], "verify_per_s": thr["verify_per_s"]})
+# verify_batch at BATCH_SIZE 100 (benches/aggregate_range_bench.rs:21,65-84): four distinct proofs, cycled
+rng = np.random.default_rng(SEED + 9)
+bvals = rng.integers(0, 1 << 63, (4, m), dtype=np.uint64)
+bgam = rng.integers(0, 1 << 64, (4, m, 4), dtype=np.uint64)
+bgam[:, :, 3] &= np.uint64((1 << 63) - 1)
+host_mirror.range_aggregate_verify_batch(ctx, bp.SECP256K1, gs, hs, ugh, bvals, bgam, n_bits, 8, SEED, SEED + 1)
+vb = host_mirror.range_aggregate_verify_batch(ctx, bp.SECP256K1, gs, hs, ugh, bvals, bgam, n_bits, 100, SEED, SEED + 1)
+assert vb["ok_device"] and vb["ok_host"]
+out["verify_batch_100"] = {"collect_ms": vb["collect_ms"], "device_merge_ms": vb["device_merge_ms"],
+                           "host_merge_ms": vb["host_merge_ms"],
+                           "batches_per_s_device_merge": 1e3 / (vb["collect_ms"] + vb["device_merge_ms"]),
+                           "proofs_per_s_device_merge": 100e3 / (vb["collect_ms"] + vb["device_merge_ms"]),
+                           "proofs_per_s_host_merge": 100e3 / (vb["collect_ms"] + vb["host_merge_ms"]),
+                           "note": "collect = 100 x verify_aux (scalars of the deferred MSM, one at a time on one context); "
+                                   "merge = the random linear combination and its single MSM"}
 print(json.dumps(out))

@@ -75,6 +75,11 @@ SIGNATURES = {
     "bp_msm_resident_plus": (ci, [vp, vp, sz, sz, vp, vp, vp, vp, vp, sz, vp]),
     "bp_msm_windows_dev": (ci, [vp, ci, vp, vp, vp, vp, sz, vp, C.POINTER(ci), C.POINTER(ci)]),
     "bp_msm_combine_windows_dev": (ci, [vp, ci, vp, ci, ci, ci, vp]),
+    "bp_batch_begin": (ci, [vp, vp, sz, C.POINTER(vp)]),
+    "bp_batch_axpy": (ci, [vp, sz, vp, sz, vp]),
+    "bp_batch_axpy_dev": (ci, [vp, sz, vp, sz, vp]),
+    "bp_batch_msm": (ci, [vp, vp, vp, vp, vp, sz, vp]),
+    "bp_batch_free": (None, [vp]),
     "bp_msm_aos": (ci, [vp, ci, vp, vp, sz, vp]),
     "bp_bases_register_aos": (ci, [vp, ci, vp, sz, C.POINTER(vp)]),
     "bp_msm_shard_window_bits": (ci, [sz, ci]),

@@ -125,6 +125,14 @@ struct bp_bases {
   u32* tab = nullptr;  // window tables (bp_bases_precompute): kTableWindows * n records of 64 bytes
 };
 
+// Accumulator of bp_batch_*: one scalar per point of a registered base set, on the device
+struct bp_batch {
+  bp_ctx* ctx;
+  const bp_bases* bases;
+  size_t n;
+  u32* acc;
+};
+
 // MSMs over at most this many points use the window tables of a base set that has them;
 // beyond, the 16-bit-window pipeline does half the additions and wins
 constexpr size_t kTableMaxPoints = (size_t)1 << 17;
@@ -768,6 +776,84 @@ int bp_msm_combine_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_windows
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   finish_windows(curve, (const uint64_t*)ctx->pinned, n_windows, window_bits, out_xyz);
   return BP_OK;
+}
+
+// ---- batched deferred MSMs over a registered base set ---------------------------------------
+
+int bp_batch_begin(bp_ctx* ctx, const bp_bases* bases, size_t n, bp_batch** out) {
+  if (!ctx || !bases || !out) return fail(ctx, BP_E_ARG, "bp_batch_begin: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_batch_begin: bases belong to another context");
+  if (n > bases->n) return fail(ctx, BP_E_ARG, "bp_batch_begin: more scalars than registered points");
+  Guard g(ctx);
+  bp_batch* b = new (std::nothrow) bp_batch{ctx, bases, n, nullptr};
+  if (!b) return fail(ctx, BP_E_OOM, "host allocation");
+  hipError_t e = hipMalloc((void**)&b->acc, n ? n * 32 : 32);
+  if (e == hipSuccess) e = hipMemsetAsync(b->acc, 0, n ? n * 32 : 32, ctx->stream);
+  if (e != hipSuccess) {
+    if (b->acc) (void)hipFree(b->acc);
+    delete b;
+    return fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "bp_batch_begin", e);
+  }
+  *out = b;
+  return BP_OK;
+}
+
+void bp_batch_free(bp_batch* b) {
+  if (!b) return;
+  Guard g(b->ctx);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  (void)hipFree(b->acc);
+  delete b;
+}
+
+namespace {
+int batch_axpy(bp_batch* b, size_t offset, const u32* d_scalars, size_t count, const uint64_t weight[4]) {
+  bp_ctx* ctx = b->ctx;
+  hipError_t e = launch_vec_op(b->bases->curve, BP_VEC_AXPY, b->acc + offset * 8, d_scalars, to_arg(weight), count,
+                               b->acc + offset * 8, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "bp_batch_axpy", e);
+  return BP_OK;
+}
+}  // namespace
+
+int bp_batch_axpy(bp_batch* b, size_t offset, const uint64_t* scalars, size_t count, const uint64_t weight[4]) {
+  if (!b || !weight || (count && !scalars)) return BP_E_ARG;
+  bp_ctx* ctx = b->ctx;
+  if (offset > b->n || count > b->n - offset) return fail(ctx, BP_E_ARG, "bp_batch_axpy: range outside the accumulator");
+  Guard g(ctx);
+  if (count == 0) return BP_OK;
+  void* ds;
+  CHK(upload(ctx, S_IN3, scalars, count * 32, &ds));
+  CHK(batch_axpy(b, offset, (const u32*)ds, count, weight));
+  // the staging buffer is reused by the next call: the host may not run ahead of this launch
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_batch_axpy_dev(bp_batch* b, size_t offset, const uint64_t* d_scalars, size_t count, const uint64_t weight[4]) {
+  if (!b || !weight || (count && !d_scalars)) return BP_E_ARG;
+  bp_ctx* ctx = b->ctx;
+  if (offset > b->n || count > b->n - offset) return fail(ctx, BP_E_ARG, "bp_batch_axpy_dev: range outside the accumulator");
+  Guard g(ctx);
+  if (count == 0) return BP_OK;
+  return batch_axpy(b, offset, (const u32*)d_scalars, count, weight);
+}
+
+int bp_batch_msm(bp_batch* b, const uint64_t* extra_x, const uint64_t* extra_y, const uint8_t* extra_inf,
+                 const uint64_t* extra_scalars, size_t n_extra, uint64_t out_xyz[12]) {
+  if (!b || !out_xyz || (n_extra && (!extra_x || !extra_y || !extra_scalars))) return BP_E_ARG;
+  bp_ctx* ctx = b->ctx;
+  Guard g(ctx);
+  void *dx = nullptr, *dy = nullptr, *di = nullptr, *des = nullptr;
+  if (n_extra) {
+    CHK(upload(ctx, S_IN0, extra_x, n_extra * 32, &dx));
+    CHK(upload(ctx, S_IN1, extra_y, n_extra * 32, &dy));
+    if (extra_inf) CHK(upload(ctx, S_IN2, extra_inf, n_extra, &di));
+    CHK(upload(ctx, S_IN4, extra_scalars, n_extra * 32, &des));
+  }
+  MsmPart p0{b->bases->x, b->bases->y, b->bases->inf, b->acc, b->n};
+  MsmPart p1{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)des, n_extra};
+  return msm_full(ctx, b->bases->curve, p0, p1, out_xyz);
 }
 
 // ---- field-vector kernels ------------------------------------------------------

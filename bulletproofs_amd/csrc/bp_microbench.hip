@@ -16,6 +16,18 @@ __global__ __launch_bounds__(256) void k_mb_mul(int iters, u32* __restrict__ io)
   if (x.v[0] == 0x12345 && y.v[3] == 0x54321) fe_store(io, x);
 }
 
+// a*b + c*d with one reduction (fe_mul2), two per step
+template <class F>
+__global__ __launch_bounds__(256) void k_mb_mul2(int iters, u32* __restrict__ io) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fe x = fe_load(io + (t & 1023) * 8), y = fe_load(io + ((t + 1) & 1023) * 8);
+  for (int i = 0; i < iters; i++) {
+    x = fe_mul2<F>(x, y, y, x);
+    y = fe_mul2<F>(y, x, x, y);
+  }
+  if (x.v[0] == 0x12345 && y.v[3] == 0x54321) fe_store(io, x);
+}
+
 template <class F>
 __global__ __launch_bounds__(256) void k_mb_addsub(int iters, u32* __restrict__ io) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,6 +115,8 @@ hipError_t launch_microbench(int id, int blocks, int iters, u32* io, hipStream_t
     case 6: hipLaunchKernelGGL(k_mb_mul<Secp256k1FqP>, dim3(blocks), dim3(256), 0, st, iters, io); break;
     case 7: hipLaunchKernelGGL(k_mb_madd<Secp256k1FqP>, dim3(blocks), dim3(128), 0, st, iters, io); break;
     case 8: hipLaunchKernelGGL(k_mb_mul_check, dim3(blocks), dim3(256), 0, st, iters, io); break;
+    case 9: hipLaunchKernelGGL(k_mb_mul<Secp256k1Fr>, dim3(blocks), dim3(256), 0, st, iters, io); break;
+    case 10: hipLaunchKernelGGL(k_mb_mul2<Secp256k1Fr>, dim3(blocks), dim3(256), 0, st, iters, io); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

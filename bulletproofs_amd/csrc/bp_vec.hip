@@ -226,6 +226,8 @@ __global__ __launch_bounds__(256) void k_svec_expand(const u32* __restrict__ tab
     // multiplication and one 32-byte store, and a block writes 8 KiB runs
     const Fe a = fe_load(table + (size_t)threadIdx.x * 8);
     const size_t n_hi = n >> lo;
+    // (two products per step were tried: 0.204 ms against 0.190 ms at 2^24; the waves of a SIMD
+    // already fill each other's issue gaps)
     for (size_t hi = blockIdx.x; hi < n_hi; hi += gridDim.x) {
       const Fe b = fe_load(table + (n_lo + hi) * 8);
       fe_store_nt(out + ((hi << lo) + threadIdx.x) * 8, fe_mul<F>(a, b));

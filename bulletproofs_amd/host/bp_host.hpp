@@ -288,6 +288,9 @@ class Msm {
     return out;
   }
   bp_ctx* ctx() const { return ctx_; }
+  const bp_bases* bases() const { return bases_; }
+  const std::vector<Scalar>& dense() const { return dense_; }
+  const std::unordered_map<Affine, Scalar, AffineHash>& map() const { return map_; }
   Msm empty_like() const { return bases_ ? Msm(ctx_, bases_, dense_.size()) : Msm(ctx_); }
 
  private:
@@ -312,6 +315,43 @@ bool verify_batch_aux(std::vector<M>& proofs, const Scalar& alpha) {
     pw = S::mul(pw, alpha);
   }
   return is_zero(acc.execute());
+}
+
+// The same check with the combination kept on the device (bp_batch_*): the accumulators must share
+// one registered base set; their dense scalars are added there with the weights alpha^k, the few
+// bases outside the set are merged in a plain accumulator on the host, and one MSM finishes.  The
+// accumulators are left unscaled.
+template <class M>
+bool verify_batch_aux_resident(const std::vector<M>& proofs, const Scalar& alpha) {
+  using S = typename M::S;
+  if (proofs.empty()) throw std::invalid_argument("non-empty vec");
+  bp_ctx* ctx = proofs[0].ctx();
+  const bp_bases* bases = proofs[0].bases();
+  const size_t n = proofs[0].dense().size();
+  if (!bases) throw std::invalid_argument("accumulators are not over a registered base set");
+  bp_batch* batch = nullptr;
+  check(ctx, bp_batch_begin(ctx, bases, n, &batch), "bp_batch_begin");
+  struct Release { bp_batch* b; ~Release() { bp_batch_free(b); } } release{batch};
+  M rest(ctx);
+  Scalar pw = S::one();
+  for (const M& p : proofs) {
+    if (p.bases() != bases || p.dense().size() != n) throw std::invalid_argument("accumulators over different base sets");
+    if (n) check(ctx, bp_batch_axpy(batch, 0, p.dense()[0].l, n, pw.l), "bp_batch_axpy");
+    for (auto& kv : p.map()) rest.upsert(kv.first, S::mul(kv.second, pw));
+    pw = S::mul(pw, alpha);
+  }
+  const size_t ne = rest.map().size();
+  std::vector<uint64_t> x(ne * 4 + 4), y(ne * 4 + 4), sc(ne * 4 + 4);
+  std::vector<uint8_t> inf(ne + 1);
+  size_t i = 0;
+  for (auto& kv : rest.map()) {
+    memcpy(&x[4 * i], kv.first.x, 32); memcpy(&y[4 * i], kv.first.y, 32); inf[i] = kv.first.inf;
+    memcpy(&sc[4 * i], kv.second.l, 32);
+    i++;
+  }
+  Projective out;
+  check(ctx, bp_batch_msm(batch, x.data(), y.data(), inf.data(), sc.data(), ne, out.xyz), "bp_batch_msm");
+  return is_zero(out);
 }
 
 // ---- transcript stand-in -------------------------------------------------------------

@@ -390,6 +390,66 @@ int range_throughput(int device, const uint64_t* gx, const uint64_t* gy, const u
   return 0;
 }
 
+// verify_batch of the reference's range benches (benches/aggregate_range_bench.rs:65-84, BATCH_SIZE 100):
+// `distinct` proofs over different values are proved once (untimed); a batch of `batch` of them (cycling)
+// is then verified: every proof's verify_aux (collect_ms), then the random linear combination and its
+// one MSM, with the combination kept on the device (device_merge_ms) and on the host as the reference
+// does it (host_merge_ms).  tamper != 0: the last proof of the batch carries t_hat + 1 and both
+// combinations must reject.  values: distinct x m, gamma: distinct x m x 4.
+template <class Fq, class Fr, int CURVE>
+int range_verify_batch(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx, const uint64_t* hy,
+                       const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma, size_t m, unsigned n_bits,
+                       uint64_t seed_rand, uint64_t seed_chal, int distinct, int batch, int tamper, double* collect_ms,
+                       double* device_merge_ms, double* host_merge_ms, int* ok_device, int* ok_host) {
+  using R = RangeAggregate<Fq, Fr, CURVE>;
+  using PO = PointOps<Fq, Fr>;
+  using M = Msm<Fq, Fr, CURVE>;
+  const size_t n = (size_t)n_bits * m;
+  typename R::Crs crs;
+  crs.ipa.gs = unpack(gx, gy, nullptr, n);
+  crs.ipa.hs = unpack(hx, hy, nullptr, n);
+  auto pt = [&](int k) { Affine a; memcpy(a.x, ugh_xy + 8 * k, 32); memcpy(a.y, ugh_xy + 8 * k + 4, 32); a.inf = 0; return a; };
+  crs.ipa.u = pt(0); crs.g = pt(1); crs.h = pt(2);
+  R::register_bases(ctx, crs, n);
+  struct Release { bp_bases* b; ~Release() { bp_bases_free(b); } } release{crs.gh};
+  struct Timing { bp_ctx* c; Timing(bp_ctx* c_) : c(c_) { bp_set_timing(c, 0); } ~Timing() { bp_set_timing(c, 1); } } timing(ctx);
+  std::vector<RangeProof> proofs(distinct);
+  std::vector<std::vector<Projective>> vcoms(distinct);
+  for (int p = 0; p < distinct; p++) {
+    std::vector<uint64_t> vals(values + (size_t)p * m, values + (size_t)(p + 1) * m);
+    std::vector<Scalar> gam = unpack_s(gamma + (size_t)p * m * 4, m);
+    vcoms[p].resize(m);
+    for (size_t j = 0; j < m; j++)
+      vcoms[p][j] = PO::lower(hx_add<Fq>(PO::mul(PO::lift(crs.g), R::from_u64(vals[j])), PO::mul(PO::lift(crs.h), gam[j])));
+    SeededTranscript<Fr> t1(seed_chal + p);
+    SeededRandom<Fr> rng(seed_rand + p);
+    proofs[p] = R::prove(ctx, crs, vals, gam, n_bits, t1, rng);
+  }
+  using clock = std::chrono::steady_clock;
+  auto t0 = clock::now();
+  std::vector<M> msms;
+  msms.reserve(batch);
+  for (int k = 0; k < batch; k++) {
+    const int p = k % distinct;
+    RangeProof pr = proofs[p];
+    if (tamper && k == batch - 1) pr.t_hat = ScalarOps<Fr>::add(pr.t_hat, ScalarOps<Fr>::one());
+    SeededTranscript<Fr> t2(seed_chal + p);
+    SeededRandom<Fr> vrng((seed_rand + p) ^ 0x5EEDull);
+    msms.push_back(R::verify_aux(ctx, crs, vcoms[p], n_bits, pr, t2, vrng));
+  }
+  auto t1 = clock::now();
+  SeededTranscript<Fr> ta(seed_chal ^ 0xA1FAull);
+  const Scalar alpha = ta.verifier_scalar();
+  *ok_device = verify_batch_aux_resident(msms, alpha) ? 1 : 0;
+  auto t2 = clock::now();
+  *ok_host = verify_batch_aux(msms, alpha) ? 1 : 0;  // scales the accumulators in place: last
+  auto t3 = clock::now();
+  *collect_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  *device_merge_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+  *host_merge_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -409,6 +469,27 @@ int bph_range_agg_throughput(int device, int curve, const uint64_t* gx, const ui
     if (curve == BP_VESTA)
       return range_throughput<VestaFq, VestaFr, BP_VESTA>(device, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits, seed_rand,
                                                          seed_chal, workers, reps, prove_wall_ms, verify_wall_ms, ok);
+    return BP_E_CURVE;
+  } catch (const std::exception&) {
+    return BP_E_HIP;
+  }
+}
+
+int bph_range_agg_verify_batch(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx,
+                               const uint64_t* hy, const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma,
+                               size_t m, unsigned n_bits, uint64_t seed_rand, uint64_t seed_chal, int distinct, int batch,
+                               int tamper, double* collect_ms, double* device_merge_ms, double* host_merge_ms, int* ok_device,
+                               int* ok_host) {
+  if (distinct < 1 || batch < 1) return BP_E_ARG;
+  try {
+    if (curve == BP_SECP256K1)
+      return range_verify_batch<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(ctx, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits,
+                                                                       seed_rand, seed_chal, distinct, batch, tamper, collect_ms,
+                                                                       device_merge_ms, host_merge_ms, ok_device, ok_host);
+    if (curve == BP_VESTA)
+      return range_verify_batch<VestaFq, VestaFr, BP_VESTA>(ctx, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits, seed_rand,
+                                                           seed_chal, distinct, batch, tamper, collect_ms, device_merge_ms,
+                                                           host_merge_ms, ok_device, ok_host);
     return BP_E_CURVE;
   } catch (const std::exception&) {
     return BP_E_HIP;

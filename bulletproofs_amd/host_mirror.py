@@ -119,6 +119,38 @@ def range_aggregate_throughput(device, curve, gs, hs, ugh_xy, values, gamma, n_b
                 prove_per_s=total / tp.value * 1e3, verify_per_s=total / tv.value * 1e3)
 
 
+hlib.bph_range_agg_verify_batch.restype = ci
+hlib.bph_range_agg_verify_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint64, C.c_uint64, ci, ci, ci,
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                            C.POINTER(ci), C.POINTER(ci)]
+
+
+def range_aggregate_verify_batch(ctx: Context, curve, gs, hs, ugh_xy, values, gamma, n_bits, batch, seed_rand=1, seed_chal=2,
+                                 tamper=False):
+    """verify_batch of the range benches (benches/aggregate_range_bench.rs:65-84): values (distinct, m) and
+    gamma (distinct, m, 4) give `distinct` proofs; a batch of `batch` verifications cycling through them is
+    collected (verify_aux each) and combined by verify_batch_aux (src/msm.rs:91-115), on the device and on
+    the host.  tamper: the last proof of the batch is corrupted and both combinations must reject."""
+    gx, gy, _ = _pts(gs)
+    hx, hy, _ = _pts(hs)
+    values = np.ascontiguousarray(values, dtype=np.uint64)
+    gamma = np.ascontiguousarray(gamma, dtype=np.uint64)
+    distinct, m = values.shape
+    assert gamma.shape == (distinct, m, 4)
+    n = m * n_bits
+    assert n & (n - 1) == 0 and gx.shape[0] >= n and hx.shape[0] >= n
+    ugh_xy = np.ascontiguousarray(ugh_xy, dtype=np.uint64).reshape(24)
+    tc, td, th = C.c_double(), C.c_double(), C.c_double()
+    okd, okh = ci(), ci()
+    rc = hlib.bph_range_agg_verify_batch(ctx.h, curve, _p(gx), _p(gy), _p(hx), _p(hy), _p(ugh_xy), _p(values), _p(gamma), m,
+                                         n_bits, seed_rand, seed_chal, distinct, batch, int(bool(tamper)), C.byref(tc),
+                                         C.byref(td), C.byref(th), C.byref(okd), C.byref(okh))
+    if rc:
+        raise RuntimeError(f"bph_range_agg_verify_batch rc={rc}")
+    return dict(ok_device=bool(okd.value), ok_host=bool(okh.value), collect_ms=tc.value, device_merge_ms=td.value,
+                host_merge_ms=th.value)
+
+
 hlib.bph_poly_roundtrip.restype = ci
 hlib.bph_poly_roundtrip.argtypes = [vp, ci, vp, vp, vp, vp, sz, sz, vp, C.c_uint64, C.c_uint64, ci, ci, vp, vp, vp, vp, vp, vp,
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci),

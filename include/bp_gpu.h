@@ -43,6 +43,7 @@ extern "C" {
 typedef struct bp_ctx bp_ctx;
 typedef struct bp_bases bp_bases;
 typedef struct bp_ipa bp_ipa;
+typedef struct bp_batch bp_batch;
 
 enum { BP_SECP256K1 = 0, BP_VESTA = 1 };
 
@@ -179,6 +180,26 @@ int bp_msm_shard_windows_dev(bp_ctx* ctx, int curve, const uint64_t* d_x, const 
 int bp_msm_shard_windows_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
                                   const uint64_t* scalars, int window_bits, uint64_t* d_windows,
                                   int* n_windows);
+
+/* ---- batch verification over a registered base set ---------------------------- */
+
+/* verify_batch_aux (src/msm.rs:91-115) for deferred MSMs whose bases are mostly points of one
+ * registered base set (a CRS): the accumulator holds one scalar per registered point on the
+ * device, every proof's scalars are added with the weight alpha^k there (Msm::scale src/msm.rs:50-54
+ * and Msm::batch :73-77 as one multiply-add per element), and the combined sum is one MSM whose
+ * bases never leave the GPU.  The few bases outside the set (proof elements, commitments) are merged
+ * by the caller and passed to bp_batch_msm with their scalars.
+ *  - bp_batch_begin: accumulator over bases[0 .. n), all zero.
+ *  - bp_batch_axpy / _dev: acc[offset + i] += weight * scalars[i], i < count (host or device scalars).
+ *  - bp_batch_msm: sum_i acc[i] * bases[i] + sum_j extra_scalars[j] * extra_j; the accumulator is
+ *    left as it is (more proofs may be added and the sum taken again). */
+int bp_batch_begin(bp_ctx* ctx, const bp_bases* bases, size_t n, bp_batch** out);
+int bp_batch_axpy(bp_batch* b, size_t offset, const uint64_t* scalars, size_t count, const uint64_t weight[4]);
+int bp_batch_axpy_dev(bp_batch* b, size_t offset, const uint64_t* d_scalars, size_t count,
+                      const uint64_t weight[4]);
+int bp_batch_msm(bp_batch* b, const uint64_t* extra_x, const uint64_t* extra_y, const uint8_t* extra_inf,
+                 const uint64_t* extra_scalars, size_t n_extra, uint64_t out_xyz[12]);
+void bp_batch_free(bp_batch* b);
 
 /* ---- field-vector kernels (host buffers) --------------------------------- */
 
@@ -342,7 +363,8 @@ int bp_bench_int_mad_peak(bp_ctx* ctx, int iters, double* mac_per_s);
  * id 6 = as 0 and id 7 = as 2 on the secp256k1 base field in its plain (non-Montgomery) form,
  * the representation the MSM pipeline uses internally; id 8 = self-check of that multiply against
  * its portable form over chains of `iters` products: *ms receives the number of lanes that
- * disagreed (0 = pass). */
+ * disagreed (0 = pass); id 9 = as 0 on the scalar field of secp256k1 (the multiply of the
+ * streaming kernels), id 10 = 2*iters dual products a*b + c*d with one reduction on that field. */
 int bp_microbench(bp_ctx* ctx, int id, int blocks, int iters, float* ms);
 /* The event markers behind bp_last_kernel_ms for MSMs (four per MSM, a few microseconds each on the
  * stream) can be turned off for latency-bound callers (the IPA rounds of a proof); on by default.

@@ -133,3 +133,58 @@ def test_poly_commit_open_verify_halo(ctx, c, n, deg):
                                             o.pack_field([r], c.n), o.pack_field([x], c.n), seed_rand=5, seed_chal=6,
                                             tamper=True, halo=False)
     assert not bad["verify_ok"] and not bad["lazy_ok"]
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_range_proof_batch_verification_on_the_device(ctx, coracle, c):
+    """verify_batch_aux (src/msm.rs:91-115) over ten range proofs of four different statements: the random
+    linear combination kept on the device (bp_batch_*) and the host's agree, accept valid batches and
+    reject a batch whose last proof is corrupted.  The batch primitives themselves against the C oracle:
+    acc = sum_k w_k * s_k, then one MSM."""
+    from bulletproofs_amd import host_mirror
+    from bulletproofs_amd._lib import lib
+    import ctypes as C
+
+    m, n_bits, distinct = 2, 8, 4
+    n = m * n_bits
+    rng = o.SplitMix64(777 + c.id)
+    gs = o.gen_points_arith(n, rng.field(c.n), rng.field(c.n), c)
+    hs = o.gen_points_arith(n, rng.field(c.n), rng.field(c.n), c)
+    u, g, h = (o.scalar_mul(rng.field(c.n), c.g, c) for _ in range(3))
+    values = np.array([[rng.next() & 0xFF for _ in range(m)] for _ in range(distinct)], dtype=np.uint64)
+    gammas = np.stack([o.pack_field(rng.scalars(m, c.n), c.n) for _ in range(distinct)])
+    ugh = np.stack([np.concatenate([o.pack_field([P[0]], c.p)[0], o.pack_field([P[1]], c.p)[0]]) for P in (u, g, h)])
+    G, H = o.pack_points(gs, c), o.pack_points(hs, c)
+    good = host_mirror.range_aggregate_verify_batch(ctx, c.id, G, H, ugh, values, gammas, n_bits, 10, 5, 6)
+    assert good["ok_device"] and good["ok_host"]
+    bad = host_mirror.range_aggregate_verify_batch(ctx, c.id, G, H, ugh, values, gammas, n_bits, 10, 5, 6, tamper=True)
+    assert not bad["ok_device"] and not bad["ok_host"]
+
+    # the primitives: three weighted scalar vectors over 300 registered points plus two outside points
+    npts = 300
+    px, py = coracle.gen_points(c.id, np.concatenate([G[0][0], G[1][0]]), np.concatenate([G[0][1], G[1][1]]), npts + 2)
+    bases = ctx.register_bases(c.id, (px[:npts], py[:npts], None))
+    vecs = [o.pack_field(rng.scalars(npts, c.n), c.n) for _ in range(3)]
+    ws = rng.scalars(3, c.n)
+    extra_s = rng.scalars(2, c.n)
+    hb = C.c_void_p()
+    assert lib.bp_batch_begin(ctx.h, bases.h, npts, C.byref(hb)) == 0
+    for v, w in zip(vecs, ws):
+        wa = o.pack_field([w], c.n)
+        assert lib.bp_batch_axpy(hb, 0, v.ctypes.data, npts, wa.ctypes.data) == 0
+    # a partial range too: acc[100 .. 150) += w0 * vecs[1][0 .. 50)
+    w0 = o.pack_field([ws[0]], c.n)
+    assert lib.bp_batch_axpy(hb, 100, vecs[1].ctypes.data, 50, w0.ctypes.data) == 0
+    assert lib.bp_batch_axpy(hb, 290, vecs[1].ctypes.data, 11, w0.ctypes.data) != 0  # outside the accumulator
+    out = np.zeros(12, dtype=np.uint64)
+    es = o.pack_field(extra_s, c.n)
+    ex, ey = np.ascontiguousarray(px[npts:]), np.ascontiguousarray(py[npts:])
+    assert lib.bp_batch_msm(hb, ex.ctypes.data, ey.ctypes.data, None, es.ctypes.data, 2, out.ctypes.data) == 0
+    lib.bp_batch_free(hb)
+    bases.free()
+    ints = [o.unpack_field(v, c.n) for v in vecs]
+    acc = [sum(w * iv[i] for w, iv in zip(ws, ints)) % c.n for i in range(npts)]
+    for i in range(50):
+        acc[100 + i] = (acc[100 + i] + ws[0] * ints[1][i]) % c.n
+    exp = coracle.msm(c.id, (px, py, None), o.pack_field(acc + extra_s, c.n), 4)
+    assert np.array_equal(out, exp)
