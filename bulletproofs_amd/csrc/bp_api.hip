@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -22,7 +23,7 @@ using namespace bp;
 namespace {
 
 enum Slot {
-  S_IN0, S_IN1, S_IN2, S_IN3, S_IN4, S_IN5, S_IN6, S_AOS,
+  S_IN0, S_IN1, S_IN2, S_IN3, S_IN4, S_IN5, S_IN6, S_AOS, S_REBASE,
   S_OUT0, S_OUT1, S_OUT2,
   S_KEYS_A, S_KEYS_B, S_VALS_A, S_VALS_B, S_SORT_TMP, S_BSTART, S_BEND, S_BUCKETS, S_SEGS,
   S_WINDOWS, S_TABLE, S_SMALL, S_NCH, S_CHOFF, S_SCAN_TMP, S_CHUNK_SUMS, S_HEAVY, S_CKEY_A, S_CKEY_B, S_CVAL_A, S_CVAL_B, S_DESC_B, S_DESC_S, S_CSORT_TMP, S_SEG_GROUPS, S_PACKED, S_RANGE, S_COUNT
@@ -133,6 +134,9 @@ struct bp_batch {
   u32* acc;
 };
 
+// sessions over at least this many generators replace them by the folded ones every few rounds
+constexpr size_t kIpaRebaseMinPoints = (size_t)1 << 15;
+
 // MSMs over at most this many points use the window tables of a base set that has them;
 // beyond, the 16-bit-window pipeline does half the additions and wins
 constexpr size_t kTableMaxPoints = (size_t)1 << 17;
@@ -155,6 +159,8 @@ struct bp_ipa {
   u32 *a = nullptr, *b = nullptr;    // current vectors (folded in place, or out of place into a2, b2 and swapped)
   u32 *a2 = nullptr, *b2 = nullptr;  // n0/2 elements each: the other side of the out-of-place fold
   bool prepped = false;              // the last fold already wrote this round's dots and MSM scalars
+  bool h_scaled = false;             // bp_ipa_scale_h was applied: the H coefficients differ from column to column
+  void* rebase_block = nullptr;      // folded generators that replaced the original ones (owned)
   u32 *cg = nullptr, *ch = nullptr;  // n0 coefficients each
   u32 *eg = nullptr, *eh = nullptr;  // n0 cross-term scalars each
   u32* u_xy = nullptr;               // the point u (x|y) when has_u
@@ -1404,6 +1410,91 @@ int ipa_begin_common(bp_ctx* ctx, int curve, int variant, const bp_bases* res, s
   return BP_OK;
 }
 
+// Replaces the session's generators by the folded ones of the current length n (see
+// launch_ipa_rebase): from here on the rounds run over n (2n with H) points instead of n0 each, the
+// coefficients start again at one and the fold history is empty.  Only for sessions whose H
+// coefficients are the same in every column (no bp_ipa_scale_h).
+int ipa_rebase(bp_ipa* s) {
+  bp_ctx* ctx = s->ctx;
+  const size_t n = s->n, n0 = s->n0, m = n0 / n;
+  const bool has_h = s->variant == BP_IPA_BULLETPROOF;
+  const int sets = has_h ? 2 : 1;
+  // the m coefficients of column 0 (the same in every column): cg[n t], ch[n t]
+  std::vector<uint64_t> coef((size_t)sets * m * 4);
+  {
+    void* d_col;
+    CHK(reserve(ctx, S_IN6, (size_t)sets * m * 32, &d_col));
+    hipError_t ge = launch_gather_column(s->cg, n, m, (u32*)d_col, ctx->stream);
+    if (ge == hipSuccess && has_h) ge = launch_gather_column(s->ch, n, m, (u32*)d_col + m * 8, ctx->stream);
+    if (ge != hipSuccess) return fail(ctx, BP_E_HIP, "gather_column", ge);
+    CHK(reserve_pinned(ctx, (size_t)sets * m * 32));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_col, (size_t)sets * m * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(coef.data(), ctx->pinned, (size_t)sets * m * 32);
+  }
+  // signed 3-bit digits of the canonical values: v = sum_w d_w 8^w, d_w in [-4, 4]
+  std::vector<int8_t> digits((size_t)sets * m * kRebaseWindows);
+  for (size_t r = 0; r < (size_t)sets * m; r++) {
+    host::HFe c;
+    memcpy(c.v, &coef[r * 4], 32);
+    c = s->curve == BP_SECP256K1 ? host::h_from_mont<Secp256k1Fr>(c) : host::h_from_mont<VestaFr>(c);
+    unsigned carry = 0;
+    for (int w = 0; w < kRebaseWindows; w++) {
+      const int bit = 3 * w;
+      unsigned v = carry;
+      if (bit < 256) {
+        unsigned raw = (unsigned)(c.v[bit >> 6] >> (bit & 63));
+        if ((bit & 63) > 61 && (bit >> 6) < 3) raw |= (unsigned)(c.v[(bit >> 6) + 1] << (64 - (bit & 63)));
+        v += raw & 7u;
+      }
+      if (v > 4) {
+        digits[r * kRebaseWindows + w] = (int8_t)((int)v - 8);
+        carry = 1;
+      } else {
+        digits[r * kRebaseWindows + w] = (int8_t)v;
+        carry = 0;
+      }
+    }
+    if (carry) return fail(ctx, BP_E_STATE, "ipa_rebase: digit overflow");  // cannot happen below 2^256
+  }
+  void *d_digits, *tmp;
+  CHK(upload(ctx, S_IN5, digits.data(), digits.size(), &d_digits));
+  CHK(reserve(ctx, S_REBASE, (size_t)sets * n * kRebaseWindows * 128, &tmp));
+  // new planes: x | y per set, then the infinity flags
+  const size_t plane = (n * 32 + 255) & ~(size_t)255;
+  void* blk = nullptr;
+  HIPCHK(ctx, hipMalloc(&blk, (size_t)sets * (2 * plane + ((n + 255) & ~(size_t)255))));
+  char* base = (char*)blk;
+  u32* ngx = (u32*)base;
+  u32* ngy = (u32*)(base + plane);
+  u32* nhx = (u32*)(base + 2 * plane);
+  u32* nhy = (u32*)(base + 3 * plane);
+  uint8_t* ngi = (uint8_t*)(base + (size_t)sets * 2 * plane);
+  uint8_t* nhi = ngi + ((n + 255) & ~(size_t)255);
+  RebaseSet rs[2] = {
+      {s->gx, s->gy, s->ginf, (const int8_t*)d_digits, (u32*)tmp, ngx, ngy, ngi},
+      {s->hx, s->hy, s->hinf, (const int8_t*)d_digits + m * kRebaseWindows, (u32*)tmp + n * kRebaseWindows * 32, nhx, nhy, nhi}};
+  hipError_t e = launch_ipa_rebase(s->curve, rs, sets, n, m, ctx->stream);
+  if (e == hipSuccess) e = launch_fill_one(s->curve, s->cg, n, ctx->stream);
+  if (e == hipSuccess && has_h) e = launch_fill_one(s->curve, s->ch, n, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(blk);
+    return fail(ctx, BP_E_HIP, "ipa_rebase", e);
+  }
+  if (s->rebase_block) (void)hipFree(s->rebase_block);
+  s->rebase_block = blk;
+  s->gx = ngx; s->gy = ngy; s->ginf = ngi;
+  if (has_h) { s->hx = nhx; s->hy = nhy; s->hinf = nhi; }
+  s->res = nullptr;  // the session no longer reads the registered base set
+  s->g_off = s->h_off = 0;
+  s->n0 = n;
+  s->x_canon.clear();
+  s->xinv_canon.clear();
+  s->prepped = false;
+  return BP_OK;
+}
+
 }  // namespace
 
 void bp_ipa_free(bp_ipa* s) {
@@ -1415,6 +1506,7 @@ void bp_ipa_free(bp_ipa* s) {
   if (any) (void)hipStreamSynchronize(s->ctx->stream);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (s->rebase_block) (void)hipFree(s->rebase_block);
   ipa_release_block(s->ctx, s->block, s->block_bytes);
   delete s;
 }
@@ -1452,6 +1544,7 @@ int bp_ipa_scale_h(bp_ipa* s, const uint64_t* scale) {
   if (s->variant != BP_IPA_BULLETPROOF) return fail(ctx, BP_E_ARG, "bp_ipa_scale_h: session has no H vector");
   if (s->n != s->n0) return fail(ctx, BP_E_STATE, "bp_ipa_scale_h: only before the first fold");
   // ch *= scale: from here on the session behaves as if H_i had been scale_i * H_i
+  s->h_scaled = true;
   HIPCHK(ctx, hipMemcpyAsync(s->eh, scale, s->n0 * 32, hipMemcpyHostToDevice, ctx->stream));
   hipError_t e = launch_vec_op(s->curve, BP_VEC_HADAMARD, s->ch, s->eh, FeArg{}, s->n0, s->ch, ctx->stream);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "bp_ipa_scale_h", e);
@@ -1596,6 +1689,20 @@ int bp_ipa_round_fold(bp_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]) {
   // The same launch folds the scalars; outputs overwrite the low halves in place (output i reads
   // only inputs i and i+h): a' = a_lo*x + a_hi*x^-1, b' = b_lo*x^-1 + b_hi*x (src/ipa/mod.rs:88-89;
   // src/poly_commit/mod.rs:96-97 writes the same pair as a_hi*u^-1 + a_lo*u, b_lo*u^-1 + b_hi*u)
+  // After a few rounds over many generators the folded generators are computed once and replace
+  // the original ones: every later round then costs an MSM over the current length instead of the
+  // first one's.  m = n0 / h original generators per folded one; BP_IPA_REBASE_M sets it (0: never).
+  static const size_t rebase_m = getenv("BP_IPA_REBASE_M") ? (size_t)atol(getenv("BP_IPA_REBASE_M")) : 16;
+  static const size_t rebase_min = getenv("BP_IPA_REBASE_MIN") ? (size_t)atol(getenv("BP_IPA_REBASE_MIN")) : kIpaRebaseMinPoints;
+  const bool rebase_due = rebase_m >= 2 && !s->h_scaled && s->n0 >= rebase_min && s->n0 / h >= rebase_m && h >= 2;
+  if (rebase_due) {
+    e = launch_ipa_round_fold(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, s->n0, h, xm, xim, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_round_fold", e);
+    s->x_canon.push_back(xc);
+    s->xinv_canon.push_back(xic);
+    s->n = h;
+    return ipa_rebase(s);
+  }
   if (h >= 2 && h / 2 <= kIpaPrepMaxHalf && h * 2 <= s->n0) {
     // short vectors, and not the first fold (a2, b2 hold n0/2 elements): fold out of place and
     // prepare the next round in the same launch; bp_ipa_round_lr then goes straight to its MSM

@@ -4,6 +4,7 @@
 // every output), so there is no divergence on the common path.
 #include "bp_curve.h"
 #include "bp_internal.h"
+#include "bp_quad.h"
 
 namespace bp {
 
@@ -189,6 +190,154 @@ hipError_t launch_normalize_jac(int curve, const u32* xyz, size_t n, u32* ox, u3
   unsigned blocks = (unsigned)((n + 255) / 256);
   DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_normalize_jac<C>, dim3(blocks), dim3(256), 0, st, xyz, n,
                                            ox, oy, oinf));
+  return hipGetLastError();
+}
+
+// ---- folded generators in one pass ("rebase") ------------------------------------------------
+// After R rounds an inner-product argument over n0 = m * n generators (m = 2^R) works, in this
+// library, with the original generators and one coefficient per generator; the folded generators
+// themselves are G'_i = sum_{t<m} s_t * G0[i + n t], i < n, with the SAME m coefficients s_t for
+// every i (products of the challenges chosen by the bits of t: src/ipa/mod.rs:80-83 applied R
+// times).  Since the scalars are shared, so are their digits: lane (i, w) walks t = 0 .. m-1, adds
+// G0[i + n t] into the bucket that digit w of s_t names -- the same bucket for all lanes of the
+// block, so the bucket choice is a uniform branch over sums kept in registers -- and leaves the
+// window sum.  3-bit signed digits (4 buckets, 86 windows).  A second launch combines the windows
+// of each output (258 doublings) and normalises.
+constexpr int kRebaseBits = 3;
+
+// up to two generator sets (G and H of one session) share the launches
+struct RebaseJob {
+  const u32* gx[2];
+  const u32* gy[2];
+  const uint8_t* ginf[2];
+  const int8_t* digits[2];  // m x kRebaseWindows each
+  u32* win[2];              // n x kRebaseWindows XYZZ points each
+  u32* ox[2];
+  u32* oy[2];
+  uint8_t* oinf[2];
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void k_rebase_windows(RebaseJob job, size_t n, size_t m) {
+  using P = typename C::Pipeline;
+  using F = typename P::Fq;
+  const int w = (int)blockIdx.y, set = (int)blockIdx.z;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32* __restrict__ gx = job.gx[set];
+  const u32* __restrict__ gy = job.gy[set];
+  const uint8_t* __restrict__ ginf = job.ginf[set];
+  const int8_t* __restrict__ digits = job.digits[set];
+  Xyzz b1 = xyzz_identity<F>(), b2 = b1, b3 = b1, b4 = b1;
+  for (size_t t = 0; t < m; t++) {
+    const int d = digits[t * kRebaseWindows + w];  // the same for every lane of the block
+    if (d == 0) continue;
+    const size_t k = i + n * t;
+    if (ginf && ginf[k]) continue;
+    const Fe x = fe_import<P>(fe_load(gx + k * 8));
+    Fe y = fe_import<P>(fe_load(gy + k * 8));
+    if (d < 0) y = fe_neg<F>(y);
+    const int a = d < 0 ? -d : d;
+    if (a == 1)
+      xyzz_madd<F>(b1, x, y);
+    else if (a == 2)
+      xyzz_madd<F>(b2, x, y);
+    else if (a == 3)
+      xyzz_madd<F>(b3, x, y);
+    else
+      xyzz_madd<F>(b4, x, y);
+  }
+  // b1 + 2 b2 + 3 b3 + 4 b4 by running sums
+  Xyzz run = b4, sum = b4;
+  xyzz_add<F>(run, b3);
+  xyzz_add<F>(sum, run);
+  xyzz_add<F>(run, b2);
+  xyzz_add<F>(sum, run);
+  xyzz_add<F>(run, b1);
+  xyzz_add<F>(sum, run);
+  u32* o = job.win[set] + ((size_t)w * n + i) * 32;
+  fe_store(o, sum.x);
+  fe_store(o + 8, sum.y);
+  fe_store(o + 16, sum.zz);
+  fe_store(o + 24, sum.zzz);
+}
+
+// sum_w 8^w * window sum, one output per quad of lanes (bp_quad.h): the chain of 258 doublings and
+// 86 additions per output is what this launch costs, and a quad runs it in about half the time of
+// one lane.  Lane 0 of the quad then normalises.
+template <class C>
+__global__ __launch_bounds__(256) void k_rebase_finish(RebaseJob job, size_t n, int sets) {
+  using P = typename C::Pipeline;
+  using F = typename P::Fq;
+  constexpr int kQuads = 64;
+  __shared__ u32 pts[kQuads * 2 * 32];  // per quad: the running value, the window sum being added
+  __shared__ u32 scr_all[kQuads * kQuadScratch * 8];
+  __shared__ u32 zero[8];
+  const u32 tid = threadIdx.x, quad = tid >> 2;
+  const int role = (int)(tid & 3u), coord = quad_coord(role);
+  u32* scr = scr_all + quad * (kQuadScratch * 8);
+  u32* acc = pts + quad * 64;
+  if (tid < 8) zero[tid] = 0;
+  const size_t o = (size_t)blockIdx.x * kQuads + quad;
+  const bool live = o < n * (size_t)sets;
+  const int set = live ? (int)(o / n) : 0;
+  const size_t i = live ? o % n : 0;
+  fe_store(acc + role * 8, quad_identity_coord(role, fe_one<F>()));
+  __syncthreads();
+  if (!live) return;
+  const u32* __restrict__ win = job.win[set];
+  for (int w = kRebaseWindows - 1; w >= 0; w--) {
+#pragma unroll 1
+    for (int k = 0; k < kRebaseBits; k++) quad_dbl<F>(acc, scr, zero, role);
+    fe_store(acc + 32 + role * 8, fe_load(win + ((size_t)w * n + i) * 32 + role * 8));
+    quad_sync();
+    Fe out;
+    const bool changed = quad_add<F>(pts, scr, zero, quad * 2, quad * 2 + 1, role, out);
+    quad_sync();
+    if (changed) fe_store(acc + coord * 8, out);
+    quad_sync();
+  }
+  if (role == 0) {
+    Xyzz v;
+    v.x = fe_load(acc);
+    v.y = fe_load(acc + 8);
+    v.zz = fe_load(acc + 16);
+    v.zzz = fe_load(acc + 24);
+    Fe x, y;
+    const bool inf = xyzz_to_affine<F>(v, x, y);
+    fe_store(job.ox[set] + i * 8, inf ? x : fe_export<P>(x));
+    fe_store(job.oy[set] + i * 8, inf ? y : fe_export<P>(y));
+    job.oinf[set][i] = inf ? 1 : 0;
+  }
+}
+
+hipError_t launch_ipa_rebase(int curve, const RebaseSet* sets, int n_sets, size_t n, size_t m, hipStream_t st) {
+  if (n == 0 || m == 0 || n_sets < 1 || n_sets > 2) return hipErrorInvalidValue;
+  RebaseJob job{};
+  for (int k = 0; k < n_sets; k++) {
+    job.gx[k] = sets[k].gx; job.gy[k] = sets[k].gy; job.ginf[k] = sets[k].ginf; job.digits[k] = sets[k].d_digits;
+    job.win[k] = sets[k].tmp_windows; job.ox[k] = sets[k].ox; job.oy[k] = sets[k].oy; job.oinf[k] = sets[k].oinf;
+  }
+  const unsigned bx = (unsigned)((n + 255) / 256);
+  const unsigned fb = (unsigned)((n * (size_t)n_sets + 63) / 64);
+  DISPATCH_CURVE(curve, {
+    hipLaunchKernelGGL(k_rebase_windows<C>, dim3(bx, kRebaseWindows, (unsigned)n_sets), dim3(256), 0, st, job, n, m);
+    hipLaunchKernelGGL(k_rebase_finish<C>, dim3(fb), dim3(256), 0, st, job, n, n_sets);
+  });
+  return hipGetLastError();
+}
+
+// dst[r] = src[r * stride_elems] (field elements): one column of a matrix of scalars
+__global__ __launch_bounds__(256) void k_gather_column(const u32* __restrict__ src, size_t stride_elems, size_t count,
+                                                       u32* __restrict__ dst) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * 8) return;
+  dst[t] = src[(t / 8) * stride_elems * 8 + (t % 8)];
+}
+
+hipError_t launch_gather_column(const u32* src, size_t stride_elems, size_t count, u32* dst, hipStream_t st) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gather_column, dim3((unsigned)((count * 8 + 255) / 256)), dim3(256), 0, st, src, stride_elems, count, dst);
   return hipGetLastError();
 }
 

@@ -101,6 +101,23 @@ hipError_t launch_window_tables(int curve, const u32* px, const u32* py, const u
                                 int n_windows, u32* table, hipStream_t st);
 hipError_t launch_normalize_jac(int curve, const u32* xyz, size_t n, u32* ox, u32* oy, uint8_t* oinf,
                                 hipStream_t st);
+// Folded generators G'_i = sum_{t<m} s_t * G0[i + n t], i < n (affine planes out), from the signed
+// 3-bit digits of the m shared coefficients (m x kRebaseWindows int8 in [-4, 4], device memory);
+// tmp_windows: n * kRebaseWindows XYZZ points (128 bytes each).  One or two sets (the G and H of a
+// session) per call.
+constexpr int kRebaseWindows = 86;
+struct RebaseSet {
+  const u32* gx;
+  const u32* gy;
+  const uint8_t* ginf;
+  const int8_t* d_digits;
+  u32* tmp_windows;
+  u32* ox;
+  u32* oy;
+  uint8_t* oinf;
+};
+hipError_t launch_ipa_rebase(int curve, const RebaseSet* sets, int n_sets, size_t n, size_t m, hipStream_t st);
+hipError_t launch_gather_column(const u32* src, size_t stride_elems, size_t count, u32* dst, hipStream_t st);
 // n records of 72 bytes {x, y, infinity byte, padding} -> planes
 hipError_t launch_aos_split(const u32* aos, size_t n, u32* x, u32* y, uint8_t* inf, hipStream_t st);
 

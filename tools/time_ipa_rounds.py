@@ -56,6 +56,14 @@ for c_win in cs:
         t0 = time.perf_counter()
         s.round_fold(ch[j:j + 1], chi[j:j + 1])
         t_fold.append(time.perf_counter() - t0)
+    # the fully folded generator equals MSM(gs, s-vector) (src/poly_commit/mod.rs:108-113)
+    G, H, Af, Bf = s.read()
+    ss = ctx.s_vector(C, ch, chi)
+    exp = ctx.msm_unchecked(C, (px[:n], py[:n], None), ss)
+    ex, ey, _ = ctx.normalize_batch(C, exp.reshape(1, 12))
+    assert np.array_equal(G[0], ex) and np.array_equal(G[1], ey), "folded generator mismatch"
     s.free()
+    print("folds (ms):", " ".join("%.3f" % (1e3 * t) for t in t_fold))
+    print("round_lr (ms):", " ".join("%.3f" % (1e3 * t) for t in t_lr))
     print("n=2^%d: round_lr wall %.3f ms (device phase %.3f ms), round_fold %.3f ms" % (
         logn, 1e3 * np.median(t_lr), np.median(dev), 1e3 * np.median(t_fold)), flush=True)
