@@ -82,3 +82,168 @@ class ShardedMsm:
         cb = self.window_bits(n_total)
         nw = bases.shard_windows(scalars, cb, self.win.data_ptr(), offset, n)
         return self._exchange(nw, cb)
+
+
+# ---- one inner-product argument over several GPUs ------------------------------------------------
+
+_FR_MODULUS = {
+    0: 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,  # secp256k1
+    1: 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001,  # vesta (its scalar field)
+}
+
+
+def _mont_one(curve):
+    import numpy as np
+
+    v = (1 << 256) % _FR_MODULUS[curve]
+    return np.array([(v >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+
+
+def dist_gather(dist, device="cuda"):
+    """gather(packet) -> (world, len(packet)) uint64 array over a torch.distributed group: one
+    all_gather_into_tensor of a few hundred bytes per rank (RCCL with device="cuda", gloo with "cpu")"""
+    import numpy as np
+    import torch
+
+    world = dist.get_world_size()
+
+    def gather(packet):
+        src = torch.from_numpy(np.ascontiguousarray(packet, dtype=np.uint64).view(np.int64)).to(device)
+        out = torch.empty(world * src.numel(), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(out, src)
+        return out.cpu().numpy().view(np.uint64).reshape(world, -1)
+
+    return gather
+
+
+class ShardedIpa:
+    """The round loop of ipa::prove (src/ipa/mod.rs:33-95) or poly_commit::prove
+    (src/poly_commit/mod.rs:69-105) with the vectors spread over `world` GPUs by residue class of the
+    index: rank r keeps the elements i = r (mod world) of G, H, a and b.  A fold pairs i with i + n/2,
+    which are in the same class as long as the half length is a multiple of world, so every rank runs
+    an ordinary session (bp_ipa_*) over its strided slice and nothing but the round's results crosses
+    between GPUs: L = sum_r L_r, R = sum_r R_r, c_l = sum_r c_l,r, c_r = sum_r c_r,r (all linear,
+    the u terms included) -- 256 bytes per rank and round in one all-gather.  When the local vectors
+    reach length one the world-many remaining elements are gathered and every rank finishes the last
+    log2(world) rounds on its own.
+
+    The rank-local and the combining halves of a round are separate methods (local_lr /
+    combine_lr, local_tail / begin_tail) so that a single process can drive several shards in
+    lockstep; round_lr and round_fold put them together around `gather`."""
+
+    def __init__(self, ctx, curve, variant, gs, hs, a, b, rank=0, world=1, gather=None, u_xy=None):
+        import numpy as np
+
+        self.np = np
+        n = len(a)
+        if world < 1 or world & (world - 1) or n % world or n & (n - 1):
+            raise ValueError("lengths and world size must be powers of two, world <= n")
+        if world > 1 and gather is None:
+            raise ValueError("more than one rank needs a gather function (see dist_gather)")
+        self.ctx, self.curve, self.variant = ctx, curve, variant
+        self.rank, self.world, self.gather = rank, world, gather
+        self.u_xy = None if u_xy is None else np.ascontiguousarray(u_xy, dtype=np.uint64).reshape(8)
+        self.n = n
+        self.one = _mont_one(curve)
+        sl = slice(rank, None, world)
+
+        def cut(P):
+            return None if P is None else tuple(None if v is None else np.ascontiguousarray(v[sl]) for v in P)
+
+        self.tail = None
+        self.local = ctx.ipa_begin(curve, variant, cut(gs), cut(hs), np.ascontiguousarray(a[sl]), np.ascontiguousarray(b[sl]))
+        if self.u_xy is not None:
+            self.local.set_u(self.u_xy)
+        # vectors no longer than the world size: the caller gathers at once (round_lr does it by itself)
+        self.wants_tail = world > 1 and n == world
+
+    def __len__(self):
+        return self.n
+
+    def _gather(self, packet):
+        return packet.reshape(1, -1) if self.world == 1 else self.gather(packet)
+
+    # -- a round's results ---------------------------------------------------------------------
+    def local_lr(self):
+        """this rank's share of the round: L_r | R_r | c_l,r | c_r,r (32 u64)"""
+        L, R, cl, cr = self.local.round_lr()
+        return self.np.concatenate([L, R, cl, cr])
+
+    def combine_lr(self, packets):
+        """sums of the shares: points by an MSM with scalars one, field elements by bp_sum"""
+        np = self.np
+        packets = np.ascontiguousarray(packets, dtype=np.uint64).reshape(self.world, 32)
+        if self.world == 1:
+            p = packets[0]
+            return p[0:12].copy(), p[12:24].copy(), p[24:28].copy(), p[28:32].copy()
+        ones = np.tile(self.one, (self.world, 1))
+        out = []
+        for off in (0, 12):
+            x = np.ascontiguousarray(packets[:, off:off + 4])
+            y = np.ascontiguousarray(packets[:, off + 4:off + 8])
+            inf = (~packets[:, off + 8:off + 12].any(axis=1)).astype(np.uint8)  # Z = 0: the identity
+            out.append(self.ctx.msm_unchecked(self.curve, (x, y, inf), ones))
+        cl = self.ctx.sum(self.curve, np.ascontiguousarray(packets[:, 24:28]))
+        cr = self.ctx.sum(self.curve, np.ascontiguousarray(packets[:, 28:32]))
+        return out[0], out[1], cl, cr
+
+    def round_lr(self):
+        if self.wants_tail:
+            self.begin_tail(self._gather(self.local_tail()))
+        if self.tail is not None:
+            return self.tail.round_lr()
+        return self.combine_lr(self._gather(self.local_lr()))
+
+    # -- the fold ------------------------------------------------------------------------------
+    def local_fold(self, x, x_inv):
+        """folds this rank's session (or the replicated tail); True when the tail has to be started"""
+        if self.tail is not None:
+            self.tail.round_fold(x, x_inv)
+            self.n //= 2
+            return False
+        self.local.round_fold(x, x_inv)
+        self.n //= 2
+        return self.world > 1 and self.n == self.world
+
+    def local_tail(self):
+        """this rank's last element: G | H | a | b as x, y, inf-flag word per point (26 u64)"""
+        np = self.np
+        G, H, a, b = self.local.read()
+        pk = np.zeros(26, dtype=np.uint64)
+        pk[0:4], pk[4:8], pk[8] = G[0][0], G[1][0], G[2][0]
+        if H is not None:
+            pk[9:13], pk[13:17], pk[17] = H[0][0], H[1][0], H[2][0]
+        pk[18:22], pk[22:26] = a[0], b[0]
+        return pk
+
+    def begin_tail(self, packets):
+        """every rank continues alone over the world-many elements that are left (rank order = index order)"""
+        np = self.np
+        p = np.ascontiguousarray(packets, dtype=np.uint64).reshape(self.world, 26)
+        G = (np.ascontiguousarray(p[:, 0:4]), np.ascontiguousarray(p[:, 4:8]), p[:, 8].astype(np.uint8))
+        H = None
+        if self.variant == 0:
+            H = (np.ascontiguousarray(p[:, 9:13]), np.ascontiguousarray(p[:, 13:17]), p[:, 17].astype(np.uint8))
+        self.tail = self.ctx.ipa_begin(self.curve, self.variant, G, H, np.ascontiguousarray(p[:, 18:22]),
+                                       np.ascontiguousarray(p[:, 22:26]))
+        if self.u_xy is not None:
+            self.tail.set_u(self.u_xy)
+        self.wants_tail = False
+        self.local.free()
+
+    def round_fold(self, x, x_inv):
+        if self.local_fold(x, x_inv):
+            self.begin_tail(self._gather(self.local_tail()))
+
+    def read(self):
+        """the current vectors: the replicated tail's, or (single rank) the session's own"""
+        s = self.tail if self.tail is not None else self.local
+        if self.tail is None and self.world > 1:
+            raise RuntimeError("vectors are spread over the ranks until their length reaches the world size")
+        return s.read()
+
+    def free(self):
+        for s in (self.tail, self.local):
+            if s is not None:
+                s.free()
+        self.tail = self.local = None

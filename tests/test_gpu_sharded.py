@@ -131,3 +131,57 @@ def test_native_sharded_example(n, shards):
     assert res.returncode == 0, res.stdout + res.stderr
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line["equal"] is True and line["shards"] == shards and line["n_total"] == n
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("n,world", [(64, 4), (8, 8), (32, 1)])
+def test_sharded_ipa_rounds_in_lockstep(ctx, c, variant, n, world):
+    """ShardedIpa: the vectors spread over `world` sessions by residue class (here all on one GPU, driven
+    in lockstep); every round's L, R, c_l, c_r equal the oracle's for the whole vectors, u terms included,
+    through the switch to the replicated tail, down to the final a, b, G, H"""
+    from gen_golden import ipa_inputs
+    from util import xyz_to_affine
+
+    from bulletproofs_amd.sharded import ShardedIpa
+
+    g, h, a, b, ch = ipa_inputs(c, n, 4100 + n + variant)
+    u = o.scalar_mul(424242, c.g, c)
+    ux, uy, _ = o.pack_points([u], c)
+    G, H = o.pack_points(g, c), (o.pack_points(h, c) if variant == 0 else None)
+    A, B = o.pack_field(a, c.n), o.pack_field(b, c.n)
+    shards = [ShardedIpa(ctx, c.id, variant, G, H, A, B, rank=r, world=world, gather=(lambda p: p) if world > 1 else None,
+                         u_xy=np.concatenate([ux[0], uy[0]])) for r in range(min(world, n))]
+    if shards[0].wants_tail:  # vectors as long as the world size: the tail starts before the first round
+        packets = np.stack([s.local_tail() for s in shards])
+        for s in shards:
+            s.begin_tail(packets)
+    gs, hs, av, bv = list(g), list(h), list(a), list(b)
+    k = n.bit_length() - 1
+    for j in range(k):
+        if shards[0].tail is None:
+            packets = np.stack([s.local_lr() for s in shards])
+            results = [s.combine_lr(packets) for s in shards]
+        else:
+            results = [s.round_lr() for s in shards]
+        eL, eR, ecl, ecr = o.ipa_round_lr(variant, gs, hs, av, bv, c)
+        eL = o.add(eL, o.scalar_mul(ecl, u, c), c)
+        eR = o.add(eR, o.scalar_mul(ecr, u, c), c)
+        for L, R, cl, cr in results:
+            assert xyz_to_affine(L, c) == eL and xyz_to_affine(R, c) == eR, j
+            assert o.unpack_field(cl, c.n)[0] == ecl and o.unpack_field(cr, c.n)[0] == ecr
+        x = ch[j]
+        X, XI = o.pack_field([x], c.n), o.pack_field([pow(x, -1, c.n)], c.n)
+        need_tail = [s.local_fold(X, XI) for s in shards]
+        if any(need_tail):
+            assert all(need_tail)
+            packets = np.stack([s.local_tail() for s in shards])
+            for s in shards:
+                s.begin_tail(packets)
+        gs, hs, av, bv = o.ipa_round_fold(variant, gs, hs, av, bv, x, c)
+    for s in shards:
+        Gf, Hf, Af, Bf = s.read()
+        assert o.unpack_points(*Gf, c) == gs and o.unpack_field(Af, c.n) == av and o.unpack_field(Bf, c.n) == bv
+        if variant == 0:
+            assert o.unpack_points(*Hf, c) == hs
+        s.free()

@@ -121,3 +121,125 @@ def test_two_rank_gloo_shard_gather_combine():
 def test_two_rank_gloo_shards_straddling_a_width_threshold():
     # 512 and 511 points: alone, the ranks would pick 8- and 4-bit windows
     assert _run(2, 1023) == [(0, True, 8), (1, True, 8)]
+
+
+# ---- sharded inner-product argument over gloo, sessions and sums backed by the Python oracle ------
+
+class _OracleSession:
+    """stand-in for api.IpaSession on CPU: the same calls, answered by the Python oracle"""
+
+    def __init__(self, oo, c, variant, gs, hs, a, b):
+        self.oo, self.c, self.variant = oo, c, variant
+        self.g = oo.unpack_points(*gs, c)
+        self.h = oo.unpack_points(*hs, c) if hs is not None else list(self.g)
+        self.a, self.b = oo.unpack_field(a, c.n), oo.unpack_field(b, c.n)
+        self.u = None
+
+    def set_u(self, u_xy):
+        x, y = self.oo.unpack_field(np.asarray(u_xy).reshape(2, 4), self.c.p)
+        self.u = (x, y)
+
+    def _xyz(self, P):
+        oo, c = self.oo, self.c
+        out = np.zeros(12, dtype=np.uint64)
+        one = oo.pack_field([1], c.p).reshape(4)
+        out[0:4] = out[4:8] = one
+        if P is not None:
+            out[0:8] = oo.pack_field([P[0], P[1]], c.p).reshape(8)
+            out[8:12] = one
+        return out
+
+    def round_lr(self):
+        oo, c = self.oo, self.c
+        L, R, cl, cr = oo.ipa_round_lr(self.variant, self.g, self.h, self.a, self.b, c)
+        if self.u is not None:
+            L = oo.add(L, oo.scalar_mul(cl, self.u, c), c)
+            R = oo.add(R, oo.scalar_mul(cr, self.u, c), c)
+        return self._xyz(L), self._xyz(R), oo.pack_field([cl], c.n).reshape(4), oo.pack_field([cr], c.n).reshape(4)
+
+    def round_fold(self, x, x_inv):
+        xv = self.oo.unpack_field(np.asarray(x).reshape(1, 4), self.c.n)[0]
+        self.g, self.h, self.a, self.b = self.oo.ipa_round_fold(self.variant, self.g, self.h, self.a, self.b, xv, self.c)
+
+    def read(self):
+        oo, c = self.oo, self.c
+        return (oo.pack_points(self.g, c), oo.pack_points(self.h, c) if self.variant == 0 else None,
+                oo.pack_field(self.a, c.n), oo.pack_field(self.b, c.n))
+
+    def free(self):
+        pass
+
+
+class _OracleCtx:
+    def __init__(self, oo, c):
+        self.oo, self.c = oo, c
+
+    def ipa_begin(self, curve, variant, gs, hs, a, b):
+        return _OracleSession(self.oo, self.c, variant, gs, hs, a, b)
+
+    def msm_unchecked(self, curve, bases, scalars):
+        oo, c = self.oo, self.c
+        pts = oo.unpack_points(bases[0], bases[1], bases[2], c)
+        P = oo.msm_naive(pts, oo.unpack_field(scalars, c.n), c)
+        return _OracleSession._xyz(self, P)
+
+    def sum(self, curve, a):
+        return self.oo.pack_field([self.oo.vsum(self.oo.unpack_field(a, self.c.n), self.c.n)], self.c.n).reshape(4)
+
+
+def _ipa_worker(rank, world, port, variant, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import bp_oracle as oo
+        from bulletproofs_amd.sharded import ShardedIpa, dist_gather
+        from gen_golden import ipa_inputs
+
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        c = oo.SECP256K1
+        n = 8
+        g, h, a, b, ch = ipa_inputs(c, n, 5150 + variant)
+        u = oo.scalar_mul(31337, c.g, c)
+        u_xy = oo.pack_field([u[0], u[1]], c.p).reshape(8)
+        s = ShardedIpa(_OracleCtx(oo, c), c.id, variant, oo.pack_points(g, c), oo.pack_points(h, c) if variant == 0 else None,
+                       oo.pack_field(a, c.n), oo.pack_field(b, c.n), rank=rank, world=world, gather=dist_gather(dist, "cpu"),
+                       u_xy=u_xy)
+        gs, hs, av, bv = list(g), list(h), list(a), list(b)
+        ok = True
+        for j in range(3):
+            L, R, cl, cr = s.round_lr()
+            eL, eR, ecl, ecr = oo.ipa_round_lr(variant, gs, hs, av, bv, c)
+            eL = oo.add(eL, oo.scalar_mul(ecl, u, c), c)
+            eR = oo.add(eR, oo.scalar_mul(ecr, u, c), c)
+            got_l = tuple(oo.unpack_field(L[:8].reshape(2, 4), c.p))
+            got_r = tuple(oo.unpack_field(R[:8].reshape(2, 4), c.p))
+            ok = ok and got_l == eL and got_r == eR and oo.unpack_field(cl.reshape(1, 4), c.n)[0] == ecl
+            x = ch[j]
+            s.round_fold(oo.pack_field([x], c.n), oo.pack_field([pow(x, -1, c.n)], c.n))
+            gs, hs, av, bv = oo.ipa_round_fold(variant, gs, hs, av, bv, x, c)
+        G, H, A, B = s.read()
+        ok = ok and oo.unpack_points(*G, c) == gs and oo.unpack_field(A, c.n) == av and oo.unpack_field(B, c.n) == bv
+        q.put((rank, bool(ok)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as exc:
+        q.put((rank, repr(exc)))
+        raise
+
+
+def test_two_rank_gloo_sharded_ipa():
+    """ShardedIpa's exchange (one all_gather per round, the switch to the replicated tail) over a real
+    two-rank group; sessions, point sums and field sums are the Python oracle's here"""
+    for variant in (0, 1):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 31500 + (os.getpid() % 2000) + variant
+        procs = [ctx.Process(target=_ipa_worker, args=(r, 2, port, variant, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        results = sorted(q.get(timeout=240) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+        assert results == [(0, True), (1, True)], results

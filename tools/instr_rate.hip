@@ -49,6 +49,10 @@ __global__ __launch_bounds__(1024) void k_rate(int iters, u64* cycles, u32* sink
         if (ID == 26) asm volatile("v_cmp_gt_u32 vcc, %1, %0\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(c[i]) : "v"(a) : "vcc");
         if (ID == 27) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(c[i]) : "v"(a));
         if (ID == 28) asm volatile("v_and_or_b32 %0, %1, %2, %0" : "+v"(c[i]) : "v"(a), "v"(b));
+        if (ID == 30) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(acc[(i + 1) & 15]), "v"(acc[(i + 2) & 15]));
+        if (ID == 31) asm volatile("v_add_f64 %0, %1, %0" : "+v"(acc[i]) : "v"(acc[(i + 1) & 15]));
+        if (ID == 32) asm volatile("v_mul_f64 %0, %1, %0" : "+v"(acc[i]) : "v"(acc[(i + 1) & 15]));
+        if (ID == 33) asm volatile("v_fma_f64 %0, %1, %2, %0\n v_fma_f64 %3, %1, %2, %3" : "+v"(acc[i]), "+v"(acc[(i + 8) & 15]) : "v"(acc[(i + 1) & 15]), "v"(acc[(i + 2) & 15]));
         if (ID == 22) asm volatile("v_pk_mul_lo_u16 %0, %1, %0" : "+v"(c[i]) : "v"(a));
         if (ID == 23) asm volatile("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(c[i]) : "v"(a), "v"(b));
       }
@@ -115,5 +119,9 @@ int main() {
   run<13>("mad + mov", 2);
   run<12>("add_co + addc", 2);
   run<21>("sub_co + subb", 2);
+  run<30>("v_fma_f64", 1);
+  run<33>("v_fma_f64 x2 same operands", 2);
+  run<31>("v_add_f64", 1);
+  run<32>("v_mul_f64", 1);
   return 0;
 }
