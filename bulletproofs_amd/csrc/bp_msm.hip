@@ -2211,7 +2211,7 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
     // of kTreeHeavyMax (the IPA rounds of a 4096-bit range proof: 8194) the blocks inside the
     // launch take every crowded bucket, nothing can be queued, and the launch for the queue is
     // left out (about 10 us of a round's chain of launches).
-    const bool no_queue = !plan.tab && plan.n_total <= kTreeHeavyMax + kTreeHeavyMax / 8 &&
+    const bool no_queue = (!plan.tab || plan.tab_virtual) && plan.n_total <= kTreeHeavyMax + kTreeHeavyMax / 8 &&
                           nbt <= (size_t)kTreeHeavyBlocks * kTreeHeavyList;
     const u32 heavy_max = no_queue && plan.n_total > kTreeHeavyMax ? (u32)plan.n_total : kTreeHeavyMax;
     // Four lanes per addition (k_bucket_quad) where few buckets hold many entries each (table plans
