@@ -1801,12 +1801,41 @@ __global__ __launch_bounds__(256) void k_window_reduce_small(const u32* __restri
 // coalesced) and join by a shuffle tree; lanes of the other blocks do the same down a column (col_lanes lanes
 // per column).  Row sum r goes to slot r-1 of the window's row array (row 0 has weight 0; the
 // last slot gets the identity), column sum q to slot q of its column array.
+// Joins the partial sums that groups of `lanes` adjacent lanes of a 256-lane block hold (lanes: a
+// power of two): on return lane 0 of every group has the group's sum.  A shuffle tree would keep
+// every wave busy for every level while half, a quarter, ... of its lanes have an addition to do;
+// here the partial sums go through LDS and the additions of a level are dealt to the first lanes
+// of the block, so a level costs as many waves as it has additions.  A level's additions read
+// slots that no addition of the same level writes, so one barrier per level is enough.  Slots are
+// 36 words apart: 16-byte accesses of neighbouring lanes then fall into different banks.
+constexpr u32 kTreeSlot = 36;
+template <class F>
+BP_DEV void group_tree_lds(Xyzz& acc, int lanes, u32* lds) {
+  if (lanes <= 1) return;
+  const int tid = (int)threadIdx.x;
+  xyzz_store_aos(lds + tid * kTreeSlot, acc);
+  __syncthreads();
+  const int groups = 256 / lanes;
+  for (int half = lanes >> 1; half > 0; half >>= 1) {
+    if (tid < groups * half) {
+      const int dst = (tid / half) * lanes + tid % half;
+      Xyzz a = xyzz_load_aos(lds + dst * kTreeSlot);
+      Xyzz o = xyzz_load_aos(lds + (dst + half) * kTreeSlot);
+      xyzz_add<F>(a, o);
+      xyzz_store_aos(lds + dst * kTreeSlot, a);
+    }
+    __syncthreads();
+  }
+  if (tid % lanes == 0) acc = xyzz_load_aos(lds + tid * kTreeSlot);
+}
+
 template <class C>
 __global__ __launch_bounds__(256) void k_rowcol_sums(const u32* __restrict__ buckets, size_t nbt, u32 n_buckets,
                                                      int n_windows, u32 row_blocks, int row_lanes, int col_lanes,
                                                      u32* __restrict__ cols, u32* __restrict__ rows,
                                                      u32* __restrict__ done) {
   using F = typename C::Fq;
+  __shared__ __attribute__((aligned(16))) u32 lds[256 * kTreeSlot];
   const u32 n_rows = n_buckets / kRowcolCols;
   // arrival counters of the launch that follows (k_rowcol_final_quad joins a window's two parts)
   if (done != nullptr && blockIdx.x == 0 && (int)threadIdx.x < n_windows) done[threadIdx.x] = 0;
@@ -1825,10 +1854,7 @@ __global__ __launch_bounds__(256) void k_rowcol_sums(const u32* __restrict__ buc
         xyzz_add<F>(acc, bk);
       }
     }
-    for (int o = row_lanes >> 1; o > 0; o >>= 1) {
-      Xyzz other = xyzz_shfl_down(acc, o, row_lanes);
-      if ((int)i < o) xyzz_add<F>(acc, other);
-    }
+    group_tree_lds<F>(acc, row_lanes, lds);
     if (live && i == 0) {
       if (r == 0) acc = xyzz_identity<F>();
       xyzz_store_soa(rows, (size_t)n_windows * n_rows, (size_t)w * n_rows + (r ? r - 1 : n_rows - 1), acc);
@@ -1846,10 +1872,7 @@ __global__ __launch_bounds__(256) void k_rowcol_sums(const u32* __restrict__ buc
         xyzz_add<F>(acc, bk);
       }
     }
-    for (int o = col_lanes >> 1; o > 0; o >>= 1) {
-      Xyzz other = xyzz_shfl_down(acc, o, col_lanes);
-      if ((int)i < o) xyzz_add<F>(acc, other);
-    }
+    group_tree_lds<F>(acc, col_lanes, lds);
     if (live && i == 0) xyzz_store_soa(cols, (size_t)n_windows * kRowcolCols, (size_t)w * kRowcolCols + q, acc);
   }
 }
