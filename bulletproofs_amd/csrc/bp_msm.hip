@@ -449,28 +449,39 @@ __global__ __launch_bounds__(1024) void k_small_front(
     fe_store(packed + i * 16, fe_import<C>(fe_load(px)));
     fe_store(packed + i * 16 + 8, fe_import<C>(fe_load(py)));
   }
+  // The block walks over the entries of its own group only (the lower or upper halves of a part
+  // whose halves go to different groups, see DigitGroups), so that every wave it runs is a full
+  // one whatever the length of the halves: entry t of the group is point `i` of the input.
+  const bool split0 = sel.half0 != 0 && sel.lo0 != sel.hi0, split1 = sel.half1 != 0 && sel.lo1 != sel.hi1;
+  size_t cnt0, cnt1;
+  {
+    const size_t q0 = split0 ? n0 / (2 * (size_t)sel.half0) : 0, r0 = split0 ? n0 % (2 * (size_t)sel.half0) : 0;
+    const size_t q1 = split1 ? n1 / (2 * (size_t)sel.half1) : 0, r1 = split1 ? n1 % (2 * (size_t)sel.half1) : 0;
+    cnt0 = !split0 ? (sel.lo0 == g ? n0 : 0)
+           : sel.hi0 == g ? q0 * sel.half0 + (r0 > sel.half0 ? r0 - sel.half0 : 0)
+           : sel.lo0 == g ? q0 * sel.half0 + (r0 < sel.half0 ? r0 : sel.half0) : 0;
+    cnt1 = !split1 ? (sel.lo1 == g ? n1 : 0)
+           : sel.hi1 == g ? q1 * sel.half1 + (r1 > sel.half1 ? r1 - sel.half1 : 0)
+           : sel.lo1 == g ? q1 * sel.half1 + (r1 < sel.half1 ? r1 : sel.half1) : 0;
+  }
+  const size_t cnt = cnt0 + cnt1 + (g < (u32)sel.n_extra ? 1 : 0);
 #pragma unroll
   for (int it = 0; it < kSmallIters; it++) {
     my_key[it] = invalid;
     my_val[it] = 0;
     my_rank[it] = 0;
-    size_t i = (size_t)it * kSmallThreads + threadIdx.x;
-    if (i >= n) continue;
-    const bool is_extra = i >= n01, second = i >= n0;
-    u32 grp;
-    {
-      const u32 half_sel = second ? sel.half1 : sel.half0;
-      if (is_extra) {
-        grp = (u32)(i - n01);
-      } else if (half_sel == 0) {
-        grp = second ? sel.lo1 : sel.lo0;
-      } else {
-        size_t li = second ? i - n0 : i;
-        bool up = (li % (2 * (size_t)half_sel)) >= half_sel;
-        grp = up ? (second ? sel.hi1 : sel.hi0) : (second ? sel.lo1 : sel.lo0);
-      }
+    const size_t t = (size_t)it * kSmallThreads + threadIdx.x;
+    if (t >= cnt) continue;
+    size_t i;
+    if (t < cnt0) {
+      i = split0 ? (t / sel.half0) * 2 * (size_t)sel.half0 + t % sel.half0 + (sel.hi0 == g ? sel.half0 : 0) : t;
+    } else if (t < cnt0 + cnt1) {
+      const size_t u = t - cnt0;
+      i = n0 + (split1 ? (u / sel.half1) * 2 * (size_t)sel.half1 + u % sel.half1 + (sel.hi1 == g ? sel.half1 : 0) : u);
+    } else {
+      i = n01 + g;
     }
-    if (grp != g) continue;
+    const bool is_extra = i >= n01, second = i >= n0;
     const u32* sp = second ? s1 + (i - n0) * 8 : s0 + i * 8;
     if (is_extra) sp = sel.extra_s[i - n01];
     const bool is_inf = is_extra ? false : (second ? (inf1 && inf1[i - n0]) : (inf0 && inf0[i]));
