@@ -1510,7 +1510,12 @@ BP_DEV void tree_heavy_block(const u32* __restrict__ packed, const u32* __restri
   }
 }
 
-template <class C>
+// QT: the lanes of a bucket are joined by additions that four lanes share (bp_quad.h) instead of a
+// shuffle tree of one-lane additions.  The tree is the dependent chain that sets the time of a small
+// launch (one wave or less per SIMD): a quad addition is 4 multiplications deep, a one-lane
+// addition 14.  Every lane leaves its partial sum in LDS; addition `task` of a level goes to quad
+// `task mod 64` of the block.
+template <class C, bool QT>
 __global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ packed, const u32* __restrict__ vals,
                                                      const u32* __restrict__ start, const u32* __restrict__ end,
                                                      size_t nbt, int lanes, u32 heavy_from, u32 heavy_max,
@@ -1544,11 +1549,43 @@ __global__ __launch_bounds__(256) void k_bucket_tree(const u32* __restrict__ pac
     if (v >> 31) qy = fe_neg<F>(qy);
     xyzz_madd<F>(acc, qx, qy);
   }
-  for (int off = lanes >> 1; off > 0; off >>= 1) {
-    Xyzz o = xyzz_shfl_down(acc, off, lanes);
-    if ((int)sub < off) xyzz_add<F>(acc, o);
+  if constexpr (!QT) {
+    for (int off = lanes >> 1; off > 0; off >>= 1) {
+      Xyzz o = xyzz_shfl_down(acc, off, lanes);
+      if ((int)sub < off) xyzz_add<F>(acc, o);
+    }
+    if (live && !is_heavy && sub == 0) xyzz_store_soa(buckets, nbt, b, acc);
+  } else {
+    __shared__ u32 pts[256 * 32];
+    __shared__ u32 scr_all[64 * kQuadScratch * 8];
+    __shared__ u32 zero[8];
+    __shared__ u32 keep[256];  // per lane group: its bucket is written by this block
+    const u32 tid = threadIdx.x, quad = tid >> 2;
+    const int role = (int)(tid & 3u), coord = quad_coord(role);
+    u32* scr = scr_all + quad * (kQuadScratch * 8);
+    if (tid < 8) zero[tid] = 0;
+    xyzz_store_aos(pts + tid * 32, acc);
+    if (sub == 0) keep[tid / (u32)lanes] = live && !is_heavy ? 1u : 0u;
+    __syncthreads();
+    const u32 groups = 256u / (u32)lanes;
+    for (u32 half = (u32)lanes >> 1; half > 0; half >>= 1) {
+      const u32 adds = groups * half;
+      for (u32 task = quad; task < adds; task += 64) {
+        const u32 dst = (task / half) * (u32)lanes + task % half;
+        Fe out;
+        const bool changed = quad_add<F>(pts, scr, zero, dst, dst + half, role, out);
+        quad_sync();
+        if (changed) fe_store(pts + dst * 32 + coord * 8, out);
+        quad_sync();
+      }
+      __syncthreads();
+    }
+    const size_t b0 = (size_t)(blockIdx.x - kTreeHeavyBlocks) * blockDim.x / (size_t)lanes;
+    for (u32 i = tid; i < groups * 4; i += blockDim.x) {
+      const u32 grp = i >> 2, c = i & 3;
+      if (keep[grp]) fe_store(buckets + ((size_t)c * nbt + b0 + grp) * 8, fe_load(pts + grp * (u32)lanes * 32 + c * 8));
+    }
   }
-  if (live && !is_heavy && sub == 0) xyzz_store_soa(buckets, nbt, b, acc);
 }
 
 // k_bucket_tree with every addition spread over four lanes (bp_quad.h): 2^log_q quads per bucket,
@@ -2248,6 +2285,11 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
     const bool no_queue = (!plan.tab || plan.tab_virtual) && plan.n_total <= kTreeHeavyMax + kTreeHeavyMax / 8 &&
                           nbt <= (size_t)kTreeHeavyBlocks * kTreeHeavyList;
     const u32 heavy_max = no_queue && plan.n_total > kTreeHeavyMax ? (u32)plan.n_total : kTreeHeavyMax;
+    // the lanes of a bucket joined by quad additions (k_bucket_tree<C, true>) while the launch is
+    // about a wave per SIMD or less, where the chain of additions sets its time; BP_MSM_TREE_JOIN=0/1
+    // forces a choice
+    static const char* join_env = getenv("BP_MSM_TREE_JOIN");
+    const bool quad_join = join_env ? atoi(join_env) != 0 : (lanes >= 2 && tree_threads <= 2 * 65536);
     // Four lanes per addition (k_bucket_quad) where few buckets hold many entries each (table plans
     // whose digit windows share a bucket set): there the chain of dependent additions sets the time.
     // With a few dozen entries per bucket the launch is bound by its total work and the one-lane tree
@@ -2278,10 +2320,14 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
                                                (const u32*)nullptr, (const u32*)nullptr));
     } else
     DISPATCH_CURVE(curve, {
-      hipLaunchKernelGGL(k_bucket_tree<C>, dim3((unsigned)((tree_threads + 255) / 256) + kTreeHeavyBlocks), dim3(256), 0,
-                         st, points,
-                         ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, lanes, heavy_from, heavy_max, idx_mask,
-                         ws.buckets, ws.heavy, ws.heavy_count);
+      if (quad_join)
+        hipLaunchKernelGGL((k_bucket_tree<C, true>), dim3((unsigned)((tree_threads + 255) / 256) + kTreeHeavyBlocks),
+                           dim3(256), 0, st, points, ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, lanes, heavy_from,
+                           heavy_max, idx_mask, ws.buckets, ws.heavy, ws.heavy_count);
+      else
+        hipLaunchKernelGGL((k_bucket_tree<C, false>), dim3((unsigned)((tree_threads + 255) / 256) + kTreeHeavyBlocks),
+                           dim3(256), 0, st, points, ws.vals_b, ws.bucket_start, ws.bucket_end, nbt, lanes, heavy_from,
+                           heavy_max, idx_mask, ws.buckets, ws.heavy, ws.heavy_count);
       if (!no_queue)
         hipLaunchKernelGGL(k_bucket_heavy_entries<C>, dim3(256), dim3(1024), 0, st, points, ws.vals_b,
                            ws.bucket_start, ws.bucket_end, nbt, idx_mask, ws.buckets, ws.heavy, ws.heavy_count);
