@@ -67,6 +67,48 @@ class Asm:
         out.append('%sasm("%s"\n%s    : "+&v"(acc), "+&v"(ovf)\n%s    : %s\n%s    : "vcc");' % (indent, body, indent, indent, ins, indent))
 
 
+class ColumnAsm:
+    """one asm statement for a whole column whose accumulator and carry count are OUTPUTS: the
+    first multiply-accumulate reads the incoming 64-bit value (or the constant 0) as its addend
+    and writes a new register pair, the first carry count sets its register.  With in/out operands
+    the compiler has to hand the statement a copy of the old carry count, which lives on as the
+    upper half of the incoming accumulator: one v_mov per column that this form does not need."""
+
+    def __init__(self, acc_in):
+        self.lines = []
+        self.inputs = []
+        self.index = {}
+        self.acc_in = acc_in  # C expression of the incoming value, None for zero
+        self.first = True
+        self.counted = False
+
+    def operand(self, constraint, expr):
+        key = (constraint, expr)
+        if key not in self.index:
+            self.index[key] = 2 + len(self.inputs)
+            self.inputs.append(key)
+        return "%%%d" % self.index[key]
+
+    def mac(self, a_ref, b_ref, carry=True):
+        if self.first:
+            addend = self.operand("v", self.acc_in) if self.acc_in else "0"
+            self.first = False
+        else:
+            addend = "%0"
+        self.lines.append("v_mad_u64_u32 %%0, vcc, %s, %s, %s" % (a_ref, b_ref, addend))
+        if carry:
+            self.lines.append("v_addc_co_u32 %%1, vcc, 0, %s, vcc" % ("%1" if self.counted else "0"))
+            self.counted = True
+
+    def emit(self, out, acc_out, ovf_out, indent="  "):
+        assert self.lines and self.counted, "a column needs a carry count to define its output"
+        assert len(self.inputs) + 2 <= 30, "asm operand limit"
+        body = "\\n\\t".join(self.lines)
+        ins = ", ".join('"%s"(%s)' % (c, e) for c, e in self.inputs)
+        out.append('%sasm("%s"\n%s    : "=&v"(%s), "=&v"(%s)\n%s    : %s\n%s    : "vcc");'
+                   % (indent, body, indent, acc_out, ovf_out, indent, ins, indent))
+
+
 def const_ref(asm, value):
     if value == 0xFFFFFFFF:
         return "-1"
@@ -170,28 +212,27 @@ def gen_secp_plain():
     out = []
     out.append("// %s: residues mod p = 2^256 - 2^32 - 977 as plain integers" % name)
     out.append("__device__ __forceinline__ Fe fe_mul_dev_%s(const Fe& a, const Fe& b) {" % name)
-    out.append("  uint64_t acc = 0;")
-    out.append("  uint32_t ovf = 0;")
+    out.append("  uint64_t acc;")
     out.append("  uint32_t h0, h1, h2, h3, h4, h5, h6, h7;")
     out.append("  Fe r;")
     for k in range(8, 15):
         out.append("  // column %d" % k)
-        ab = Asm(fresh_ovf=True)
+        ab = ColumnAsm(None if k == 8 else "acc")
         first = k == 8  # the accumulator starts at zero: one product cannot overflow it
         for i in range(8):
             j = k - i
             if 0 <= j <= 7:
                 ab.mac(ab.operand("v", "a.v[%d]" % i), ab.operand("v", "b.v[%d]" % j), carry=not first)
                 first = False
-        ab.emit(out)
-        out.append("  h%d = (uint32_t)acc;" % (k - 8))
-        out.append("  acc = (acc >> 32) | ((uint64_t)ovf << 32);")
+        out.append("  uint64_t acc%d;" % k)
+        out.append("  uint32_t ovf%d;" % k)
+        ab.emit(out, "acc%d" % k, "ovf%d" % k)
+        out.append("  h%d = (uint32_t)acc%d;" % (k - 8, k))
+        out.append("  acc = (acc%d >> 32) | ((uint64_t)ovf%d << 32);" % (k, k))
     out.append("  h7 = (uint32_t)acc;  // column 15: the upper half of a 512-bit product has 256 bits")
-    out.append("  acc = 0;")
-    out.append("  ovf = 0;")
     for k in range(8):
         out.append("  // column %d, with 977*h%d%s" % (k, k, " + h%d" % (k - 1) if k else ""))
-        ab = Asm(fresh_ovf=True)
+        ab = ColumnAsm("acc" if k else None)
         # the fold terms first: carry of the last column (< 2^37) + 977 h_k (< 2^42) + h_(k-1)
         # stays far below 2^64, so these two need no carry count
         ab.mac(ab.operand("v", "h%d" % k), ab.operand("s", "977u"), carry=False)
@@ -201,9 +242,11 @@ def gen_secp_plain():
             j = k - i
             if 0 <= j <= 7:
                 ab.mac(ab.operand("v", "a.v[%d]" % i), ab.operand("v", "b.v[%d]" % j))
-        ab.emit(out)
-        out.append("  r.v[%d] = (uint32_t)acc;" % k)
-        out.append("  acc = (acc >> 32) | ((uint64_t)ovf << 32);")
+        out.append("  uint64_t acc%d;" % k)
+        out.append("  uint32_t ovf%d;" % k)
+        ab.emit(out, "acc%d" % k, "ovf%d" % k)
+        out.append("  r.v[%d] = (uint32_t)acc%d;" % (k, k))
+        out.append("  acc = (acc%d >> 32) | ((uint64_t)ovf%d << 32);" % (k, k))
     out.append("  return fe_plain_secp_finish(r, acc + h7);")
     out.append("}")
     return out
