@@ -94,6 +94,10 @@ struct bp_ctx {
   DevBuf buf[S_COUNT];
   void* pinned = nullptr;
   size_t pinned_cap = 0;
+  // 64 slots of 64 bytes of pinned host memory, one per IPA session while it lives: the launch that
+  // takes a round's two inner products writes them there as well, so no copy command follows the MSM
+  void* host_slots = nullptr;
+  uint64_t host_slots_free = ~0ull;
   hipEvent_t ev[6] = {};
   int c_override = 0;
   float last_ms[3] = {0, 0, 0};
@@ -173,6 +177,8 @@ struct bp_ipa {
   const bp_bases* res = nullptr;     // generators live in this base set (not owned)
   size_t g_off = 0, h_off = 0;
   u32* dots = nullptr;               // partial sums and results of the two inner products
+  int host_slot = -1;                // slot of ctx->host_slots that receives c_l, c_r (-1: none free, copy instead)
+  bool dots_on_host = false;         // the launch that prepared this round wrote c_l, c_r to the slot
   // folded generators, materialised on demand (n0/2 points each)
   u32 *fgx = nullptr, *fgy = nullptr, *fhx = nullptr, *fhy = nullptr;
   uint8_t *fginf = nullptr, *fhinf = nullptr;
@@ -293,9 +299,13 @@ void finish_windows(int curve, const uint64_t* win, int n_windows, int c, uint64
     host::hj_combine_windows<host::MontOps<VestaFq>>(win, n_windows, c, out_xyz);
 }
 
-// device phase of an MSM: leaves plan->n_windows XYZZ window sums in S_WINDOWS
+// device phase of an MSM: leaves plan->n_windows XYZZ window sums in S_WINDOWS or, with win_host, in
+// the context's pinned host buffer (the last launch writes them there itself: they are only ever
+// written, and the caller that wants them on the host needs no copy command after the launches;
+// room for `host_extra` more bytes is kept behind them)
 int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, MsmPlan* plan,
-               u32** d_windows, int groups = 1, const MsmExtra* extra = nullptr, const MsmTable* table = nullptr) {
+               u32** d_windows, int groups = 1, const MsmExtra* extra = nullptr, const MsmTable* table = nullptr,
+               bool win_host = false, size_t host_extra = 0) {
   size_t n = p0.n + p1.n + (extra ? 2 : 0);
   hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan, table ? table->stride : 0, true);
   if (e != hipSuccess) return fail(ctx, BP_E_ARG, "msm plan (n too large?)", e);
@@ -324,7 +334,12 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
   CHK(reserve(ctx, S_HEAVY, plan->nch_bytes + 256, &p)); ws.heavy = (u32*)p + 64; ws.heavy_count = (u32*)p;
   CHK(reserve(ctx, S_SEGS, plan->seg_bytes, &p)); ws.segs = (u32*)p;
   CHK(reserve(ctx, S_SEG_GROUPS, plan->seg_group_bytes, &p)); ws.seg_groups = (u32*)p;
-  CHK(reserve(ctx, S_WINDOWS, plan->win_bytes, &p)); ws.windows = (u32*)p;
+  if (win_host) {
+    CHK(reserve_pinned(ctx, plan->win_bytes + host_extra));
+    ws.windows = (u32*)ctx->pinned;
+  } else {
+    CHK(reserve(ctx, S_WINDOWS, plan->win_bytes, &p)); ws.windows = (u32*)p;
+  }
   // four event markers per MSM cost a few microseconds each on the stream: only with timing on
   const bool timed = ctx->timing || plan->stages > 1;
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
@@ -356,9 +371,7 @@ int msm_full(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, uint6
              const MsmTable* table = nullptr) {
   MsmPlan plan;
   u32* d_win = nullptr;
-  CHK(msm_device(ctx, curve, p0, p1, &plan, &d_win, 1, nullptr, table));
-  CHK(reserve_pinned(ctx, plan.win_bytes));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CHK(msm_device(ctx, curve, p0, p1, &plan, &d_win, 1, nullptr, table, true));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   msm_collect_times(ctx, plan.n_total != 0);
   finish_windows(curve, (const uint64_t*)ctx->pinned, plan.n_windows, plan.finish_c, out_xyz);
@@ -422,6 +435,11 @@ int bp_init(int device, bp_ctx** out) {
       return BP_E_HIP;
     }
   }
+  if (hipHostMalloc(&c->host_slots, 64 * 64, hipHostMallocDefault) != hipSuccess) {
+    c->host_slots = nullptr;
+    bp_shutdown(c);
+    return BP_E_HIP;
+  }
   // address of this device's copy of the static scratch array (the device is current: hipSetDevice above)
   {
     void* p = nullptr;
@@ -442,6 +460,7 @@ void bp_shutdown(bp_ctx* ctx) {
   for (auto& b : ctx->buf)
     if (b.p) (void)hipFree(b.p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->host_slots) (void)hipHostFree(ctx->host_slots);
   if (ctx->ipa_cache) (void)hipFree(ctx->ipa_cache);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
@@ -663,9 +682,7 @@ int bp_msm_resident_pair(bp_ctx* ctx, const bp_bases* bases, size_t offset, size
   p1.group_lo = p1.group_hi = 1;
   MsmPlan plan;
   u32* d_win = nullptr;
-  CHK(msm_device(ctx, bases->curve, p0, p1, &plan, &d_win, 2));
-  CHK(reserve_pinned(ctx, plan.win_bytes));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CHK(msm_device(ctx, bases->curve, p0, p1, &plan, &d_win, 2, nullptr, nullptr, true));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   msm_collect_times(ctx, plan.n_total != 0);
   const int curve = bases->curve, gw = plan.group_windows, c = plan.finish_c;
@@ -1373,6 +1390,10 @@ int ipa_begin_common(bp_ctx* ctx, int curve, int variant, const bp_bases* res, s
   if (has_h) { s->ch = at(l.ch); s->eh = at(l.eh); }
   s->u_xy = at(l.u);
   s->dots = at(l.dots);
+  if (ctx->host_slots && ctx->host_slots_free) {
+    s->host_slot = __builtin_ctzll(ctx->host_slots_free);
+    ctx->host_slots_free &= ~(1ull << s->host_slot);
+  }
   hipError_t e = hipSuccess;
   auto put = [&](void* d, const void* h, size_t bytes) {
     if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream);
@@ -1403,6 +1424,7 @@ int ipa_begin_common(bp_ctx* ctx, int curve, int variant, const bp_bases* res, s
   if (e != hipSuccess) {
     int code = fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "bp_ipa_begin", e);
     ipa_release_block(ctx, s->block, s->block_bytes);
+    if (s->host_slot >= 0) ctx->host_slots_free |= 1ull << s->host_slot;
     delete s;
     return code;
   }
@@ -1508,6 +1530,7 @@ void bp_ipa_free(bp_ipa* s) {
     if (p) (void)hipFree(p);
   if (s->rebase_block) (void)hipFree(s->rebase_block);
   ipa_release_block(s->ctx, s->block, s->block_bytes);
+  if (s->host_slot >= 0) s->ctx->host_slots_free |= 1ull << s->host_slot;
   delete s;
 }
 
@@ -1604,6 +1627,7 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
   u32* part_r = part_l + (size_t)kDotBlocks * 8;
   u32 *d_cl = part_r + (size_t)kDotBlocks * 8, *d_cr = d_cl + 8, *d_scaled = d_cl + 16;
   hipError_t e;
+  u32* host_dots = s->host_slot >= 0 ? (u32*)((char*)ctx->host_slots + (size_t)s->host_slot * 64) : nullptr;
   if (s->prepped) {
     // the fold that led here left c_l, c_r and the MSM scalars of this round (k_ipa_fold_prep)
     s->prepped = false;
@@ -1611,9 +1635,11 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
     // short vectors: a round is a chain of launches, so dots, scaling and MSM scalars share one
     const bool scaled = s->has_u && s->u_scaled;
     e = launch_ipa_round_prep(s->curve, s->a, s->b, s->cg, has_h ? s->ch : nullptr, n0, h,
-                              scaled ? s->u_factor : FeArg{}, scaled ? 1 : 0, s->eg, s->eh, d_cl, ctx->stream);
+                              scaled ? s->u_factor : FeArg{}, scaled ? 1 : 0, s->eg, s->eh, d_cl, host_dots, ctx->stream);
     if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_round_prep", e);
+    s->dots_on_host = host_dots != nullptr;
   } else {
+    s->dots_on_host = false;
     e = launch_inner_product(s->curve, a_lo, b_hi, h, part_l, d_cl, ctx->stream);
     if (e == hipSuccess) e = launch_inner_product(s->curve, a_hi, b_lo, h, part_r, d_cr, ctx->stream);
     if (e == hipSuccess && s->has_u && s->u_scaled)
@@ -1650,11 +1676,16 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
   }
   MsmPlan plan;
   u32* d_win = nullptr;
-  CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2, s->has_u ? &extra : nullptr, use_table));
-  CHK(reserve_pinned(ctx, plan.win_bytes + 64));
+  // the window sums arrive in pinned host memory straight from the last launch, c_l and c_r from
+  // the launch that took them (or, for long vectors and when no slot was free, by one copy)
+  CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2, s->has_u ? &extra : nullptr, use_table, true, 64));
   char* host = (char*)ctx->pinned;
-  HIPCHK(ctx, hipMemcpyAsync(host, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(host + plan.win_bytes, d_cl, 64, hipMemcpyDeviceToHost, ctx->stream));  // c_l, c_r
+  const char* host_c = host + plan.win_bytes;
+  if (s->dots_on_host)
+    host_c = (const char*)host_dots;
+  else
+    HIPCHK(ctx, hipMemcpyAsync(host + plan.win_bytes, d_cl, 64, hipMemcpyDeviceToHost, ctx->stream));  // c_l, c_r
+  s->dots_on_host = false;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   msm_collect_times(ctx, true);
   const uint64_t* win = (const uint64_t*)host;
@@ -1668,8 +1699,8 @@ int bp_ipa_round_lr(bp_ipa* s, uint64_t l_xyz[12], uint64_t r_xyz[12], uint64_t 
     else
       finish_windows(curve, win_r, gw, c, r_xyz);
   }
-  memcpy(c_l, host + plan.win_bytes, 32);
-  memcpy(c_r, host + plan.win_bytes + 32, 32);
+  memcpy(c_l, host_c, 32);
+  memcpy(c_r, host_c + 32, 32);
   return BP_OK;
 }
 
@@ -1708,9 +1739,11 @@ int bp_ipa_round_fold(bp_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]) {
     // prepare the next round in the same launch; bp_ipa_round_lr then goes straight to its MSM
     const bool scaled = s->has_u && s->u_scaled;
     u32* d_cl = s->dots + (size_t)2 * kDotBlocks * 8;
+    u32* host_dots = s->host_slot >= 0 ? (u32*)((char*)ctx->host_slots + (size_t)s->host_slot * 64) : nullptr;
     e = launch_ipa_fold_prep(s->curve, s->a, s->b, s->a2, s->b2, s->cg, has_h ? s->ch : nullptr, s->n0, h, xm, xim,
-                             scaled ? s->u_factor : FeArg{}, scaled ? 1 : 0, s->eg, s->eh, d_cl, ctx->stream);
+                             scaled ? s->u_factor : FeArg{}, scaled ? 1 : 0, s->eg, s->eh, d_cl, host_dots, ctx->stream);
     if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_fold_prep", e);
+    s->dots_on_host = host_dots != nullptr;
     std::swap(s->a, s->a2);
     std::swap(s->b, s->b2);
     s->prepped = true;
@@ -1753,9 +1786,7 @@ int bp_ipa_read(bp_ipa* s, uint64_t* gx, uint64_t* gy, uint8_t* ginf, uint64_t* 
       ph.tab_offset = s->h_off;
       use_table = &table;
     }
-    CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2, nullptr, use_table));
-    CHK(reserve_pinned(ctx, plan.win_bytes));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, d_win, plan.win_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CHK(msm_device(ctx, s->curve, pg, ph, &plan, &d_win, 2, nullptr, use_table, true));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t* win = (const uint64_t*)ctx->pinned;
     uint64_t g_xyz[12], h_xyz[12];

@@ -56,15 +56,17 @@ hipError_t launch_range_eval(int curve, const u32* l0, const u32* l1, const u32*
 hipError_t launch_ipa_round_fold(int curve, u32* a, u32* b, u32* cg, u32* ch, size_t n0, size_t half, FeArg x,
                                  FeArg x_inv, hipStream_t st);
 // both inner products of a round (one block), their multiples by `factor` when scale != 0, and the
-// MSM scalars in one launch; half <= kIpaPrepMaxHalf.  dots: c_l, c_r, factor*c_l, factor*c_r
+// MSM scalars in one launch; half <= kIpaPrepMaxHalf.  dots: c_l, c_r, factor*c_l, factor*c_r;
+// host_dots (may be null): 64 bytes of host memory the device can write, which also receive c_l, c_r
 constexpr size_t kIpaPrepMaxHalf = 16384;
 hipError_t launch_ipa_round_prep(int curve, const u32* a, const u32* b, const u32* cg, const u32* ch, size_t n0,
-                                 size_t half, FeArg factor, int scale, u32* eg, u32* eh, u32* dots, hipStream_t st);
+                                 size_t half, FeArg factor, int scale, u32* eg, u32* eh, u32* dots, u32* host_dots,
+                                 hipStream_t st);
 // bp_ipa_round_fold and the launch_ipa_round_prep of the next round in one launch; (a, b) are folded
 // out of place into (a2, b2), half = length of the folded vectors >= 2, half / 2 <= kIpaPrepMaxHalf
 hipError_t launch_ipa_fold_prep(int curve, const u32* a, const u32* b, u32* a2, u32* b2, u32* cg, u32* ch, size_t n0,
                                 size_t half, FeArg x, FeArg x_inv, FeArg factor, int scale, u32* eg, u32* eh, u32* dots,
-                                hipStream_t st);
+                                u32* host_dots, hipStream_t st);
 hipError_t launch_ipa_scalars(int curve, const u32* a, const u32* b, const u32* cg, const u32* ch, size_t n0,
                               size_t half, u32* eg, u32* eh, hipStream_t st);
 hipError_t launch_fill_one(int curve, u32* v, size_t n, hipStream_t st);

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(1024) void k_ipa_round_prep(const u32* __restrict__
                                                          const u32* __restrict__ cg, const u32* __restrict__ ch,
                                                          size_t n0, size_t half, FeArg factor, int scale,
                                                          u32* __restrict__ eg, u32* __restrict__ eh,
-                                                         u32* __restrict__ dots) {
+                                                         u32* __restrict__ dots, u32* __restrict__ host_dots) {
   if (blockIdx.x == 0) {
     __shared__ u32 lds[2 * 16 * 8];
     Fe accl = fe_zero(), accr = fe_zero();
@@ -599,6 +599,10 @@ __global__ __launch_bounds__(1024) void k_ipa_round_prep(const u32* __restrict__
     if (threadIdx.x == 0) {
       fe_store(dots, tl);
       fe_store(dots + 8, tr);
+      if (host_dots) {  // the caller's copy, in host memory the device can write: no copy command later
+        fe_store(host_dots, tl);
+        fe_store(host_dots + 8, tr);
+      }
       if (scale) {
         const Fe f = arg_to_fe(factor);
         fe_store(dots + 16, fe_mul<F>(tl, f));
@@ -629,7 +633,7 @@ __global__ __launch_bounds__(1024) void k_ipa_fold_prep(const u32* __restrict__ 
                                                         u32* __restrict__ cg, u32* __restrict__ ch, size_t n0,
                                                         size_t half, FeArg xa, FeArg xia, FeArg factor, int scale,
                                                         u32* __restrict__ eg, u32* __restrict__ eh,
-                                                        u32* __restrict__ dots) {
+                                                        u32* __restrict__ dots, u32* __restrict__ host_dots) {
   const Fe x = arg_to_fe(xa), xi = arg_to_fe(xia);
   const size_t q = half / 2;  // half of the next round
   if (blockIdx.x == 0) {
@@ -652,6 +656,10 @@ __global__ __launch_bounds__(1024) void k_ipa_fold_prep(const u32* __restrict__ 
     if (threadIdx.x == 0) {
       fe_store(dots, tl);
       fe_store(dots + 8, tr);
+      if (host_dots) {  // the caller's copy, in host memory the device can write: no copy command later
+        fe_store(host_dots, tl);
+        fe_store(host_dots + 8, tr);
+      }
       if (scale) {
         const Fe f = arg_to_fe(factor);
         fe_store(dots + 16, fe_mul<F>(tl, f));
@@ -710,21 +718,22 @@ hipError_t launch_ipa_round_fold(int curve, u32* a, u32* b, u32* cg, u32* ch, si
 }
 
 hipError_t launch_ipa_round_prep(int curve, const u32* a, const u32* b, const u32* cg, const u32* ch, size_t n0,
-                                 size_t half, FeArg factor, int scale, u32* eg, u32* eh, u32* dots, hipStream_t st) {
+                                 size_t half, FeArg factor, int scale, u32* eg, u32* eh, u32* dots, u32* host_dots,
+                                 hipStream_t st) {
   if (half > kIpaPrepMaxHalf) return hipErrorInvalidValue;
   unsigned blocks = 1 + (unsigned)((n0 + 1023) / 1024);
   DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipa_round_prep<F>, dim3(blocks), dim3(1024), 0, st, a, b, cg, ch, n0, half,
-                                        factor, scale, eg, eh, dots));
+                                        factor, scale, eg, eh, dots, host_dots));
   return hipGetLastError();
 }
 
 hipError_t launch_ipa_fold_prep(int curve, const u32* a, const u32* b, u32* a2, u32* b2, u32* cg, u32* ch, size_t n0,
                                 size_t half, FeArg x, FeArg x_inv, FeArg factor, int scale, u32* eg, u32* eh, u32* dots,
-                                hipStream_t st) {
+                                u32* host_dots, hipStream_t st) {
   if (half < 2 || half / 2 > kIpaPrepMaxHalf) return hipErrorInvalidValue;
   unsigned blocks = 1 + (unsigned)((n0 + 1023) / 1024);
   DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipa_fold_prep<F>, dim3(blocks), dim3(1024), 0, st, a, b, a2, b2, cg, ch, n0, half,
-                                        x, x_inv, factor, scale, eg, eh, dots));
+                                        x, x_inv, factor, scale, eg, eh, dots, host_dots));
   return hipGetLastError();
 }
 
