@@ -247,3 +247,53 @@ class ShardedIpa:
             if s is not None:
                 s.free()
         self.tail = self.local = None
+
+
+# ---- the fold of deferred checks over several GPUs -----------------------------------------------
+
+def _limbs_to_int(v):
+    return sum(int(x) << (64 * i) for i, x in enumerate(v))
+
+
+def _int_to_limbs(v):
+    import numpy as np
+
+    return np.array([(v >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+
+
+def fold_todos_witness_shard(ctx, curve, challenges, challenge_inverses, weights, rank=0, world=1):
+    """This rank's share of fold_todos_witness (src/poly_commit/mod.rs:228-244): the elements
+    i = rank (mod world) of sum_m weights[m] * coeffs(h_poly_m), in index order -- the slice a
+    ShardedIpa over the folded witness keeps on this rank, so the witness is built where it is used
+    and nothing crosses between GPUs.
+
+    coeffs(h_poly)_i = prod_j (bit j of i ? u[k-1-j] : u[k-1-j]^-1) (src/poly_commit/mod.rs:194-219):
+    the low log2(world) bits of i are the rank's, so on a residue class the vector is the s-vector of
+    the first k - log2(world) challenges times one constant per deferred check, which goes into that
+    check's weight.  challenges, challenge_inverses: (m, k, 4); weights: (m, 4) (the powers of alpha);
+    all Montgomery limbs.  Returns (2^k / world, 4)."""
+    import numpy as np
+
+    ch = np.ascontiguousarray(challenges, dtype=np.uint64)
+    chi = np.ascontiguousarray(challenge_inverses, dtype=np.uint64)
+    w = np.ascontiguousarray(weights, dtype=np.uint64).reshape(-1, 4)
+    if ch.ndim != 3 or ch.shape != chi.shape or ch.shape[2] != 4 or ch.shape[0] != w.shape[0] or ch.shape[0] == 0:
+        raise ValueError("challenges must be (m, k, 4) with m >= 1, one weight per deferred check")
+    m, k = ch.shape[0], ch.shape[1]
+    if world < 1 or world & (world - 1) or world > (1 << k) or not 0 <= rank < world:
+        raise ValueError("world must be a power of two no larger than 2^k, 0 <= rank < world")
+    t = world.bit_length() - 1
+    p = _FR_MODULUS[curve]
+    r_inv = pow(1 << 256, -1, p)  # Montgomery limbs hold v * 2^256: a product of two carries one factor too many
+    scaled = np.empty_like(w)
+    total = 0
+    for i in range(m):
+        acc = _limbs_to_int(w[i])
+        for j in range(t):
+            f = ch[i, k - 1 - j] if (rank >> j) & 1 else chi[i, k - 1 - j]
+            acc = acc * _limbs_to_int(f) * r_inv % p
+        scaled[i] = _int_to_limbs(acc)
+        total = (total + acc) % p
+    if k == t:  # one element per rank: the s-vector of no challenges is (1)
+        return _int_to_limbs(total).reshape(1, 4)
+    return ctx.fold_s_vectors(curve, np.ascontiguousarray(ch[:, :k - t]), np.ascontiguousarray(chi[:, :k - t]), scaled)

@@ -185,3 +185,28 @@ def test_sharded_ipa_rounds_in_lockstep(ctx, c, variant, n, world):
         if variant == 0:
             assert o.unpack_points(*Hf, c) == hs
         s.free()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("k,world", [(10, 8), (3, 8), (12, 2), (6, 1)])
+def test_fold_todos_witness_shards_interleave_to_the_whole(ctx, c, k, world):
+    """fold_todos_witness_shard on the device: rank r's slice is elements r, r + world, ... of the fold of
+    the whole deferred checks (bp_fold_s_vectors over all k challenges, itself checked against the oracle)"""
+    from bulletproofs_amd.sharded import fold_todos_witness_shard
+
+    rng = o.SplitMix64(0x70D0 + 16 * k + world + c.id)
+    m = 3
+    ch = [[rng.field(c.n) or 1 for _ in range(k)] for _ in range(m)]
+    alpha = rng.field(c.n)
+    w = [pow(alpha, i, c.n) for i in range(m)]
+    CH = np.stack([o.pack_field(r, c.n) for r in ch])
+    CHI = np.stack([o.pack_field([pow(x, -1, c.n) for x in r], c.n) for r in ch])
+    W = o.pack_field(w, c.n)
+    full = ctx.fold_s_vectors(c.id, CH, CHI, W)
+    expect = [0] * (1 << k)
+    for i in range(m):
+        expect = [(a + w[i] * s) % c.n for a, s in zip(expect, o.s_vector(ch[i], c.n))]
+    assert o.unpack_field(full, c.n) == expect
+    for rank in range(world):
+        got = fold_todos_witness_shard(ctx, c.id, CH, CHI, W, rank, world)
+        assert np.array_equal(got, full[rank::world]), (rank, world)

@@ -243,3 +243,50 @@ def test_two_rank_gloo_sharded_ipa():
         for p in procs:
             p.join(timeout=60)
         assert results == [(0, True), (1, True)], results
+
+
+# ---- the fold of deferred checks by residue class of the index ------------------------------------
+
+class _OracleFoldCtx:
+    """stand-in for api.Context.fold_s_vectors on CPU: the weighted sum of s-vectors by the Python oracle"""
+
+    def __init__(self, oo, c):
+        self.oo, self.c = oo, c
+
+    def fold_s_vectors(self, curve, challenges, challenge_inverses, weights):
+        oo, c = self.oo, self.c
+        m, k = challenges.shape[0], challenges.shape[1]
+        acc = [0] * (1 << k)
+        for i in range(m):
+            ch = oo.unpack_field(challenges[i], c.n) if k else []
+            assert (oo.unpack_field(challenge_inverses[i], c.n) if k else []) == [pow(x, -1, c.n) for x in ch]
+            w = oo.unpack_field(weights[i:i + 1], c.n)[0]
+            acc = [(a + w * s) % c.n for a, s in zip(acc, oo.s_vector(ch, c.n))]
+        return oo.pack_field(acc, c.n)
+
+
+def test_fold_todos_witness_by_residue_class():
+    """fold_todos_witness_shard: the slices of all ranks, interleaved, are fold_todos_witness
+    (src/poly_commit/mod.rs:228-244) of the whole deferred checks, for every world size up to the
+    vector length; the rank's constant is folded into the weights on the host"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bp_oracle as oo
+    from bulletproofs_amd.sharded import fold_todos_witness_shard
+
+    for c in (oo.SECP256K1, oo.VESTA):
+        rng = oo.SplitMix64(0x70D05 + c.id)
+        m, k = 3, 4
+        ch = [[rng.field(c.n) or 1 for _ in range(k)] for _ in range(m)]
+        alpha = rng.field(c.n)
+        w = [pow(alpha, i, c.n) for i in range(m)]
+        full = [0] * (1 << k)
+        for i in range(m):
+            full = [(a + w[i] * s) % c.n for a, s in zip(full, oo.s_vector(ch[i], c.n))]
+        CH = np.stack([oo.pack_field(r, c.n) for r in ch])
+        CHI = np.stack([oo.pack_field([pow(x, -1, c.n) for x in r], c.n) for r in ch])
+        W = oo.pack_field(w, c.n)
+        ctx = _OracleFoldCtx(oo, c)
+        for world in (1, 2, 4, 16):
+            for rank in range(world):
+                got = fold_todos_witness_shard(ctx, c.id, CH, CHI, W, rank, world)
+                assert oo.unpack_field(got, c.n) == full[rank::world], (c.name, world, rank)
