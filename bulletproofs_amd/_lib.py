@@ -111,6 +111,7 @@ SIGNATURES = {
     "bp_bases_precompute": (ci, [vp]),
     "bp_msm_resident_s_vector": (ci, [vp, vp, sz, vp, vp, sz, vp]),
     "bp_ipa_begin_resident": (ci, [vp, vp, ci, sz, sz, vp, vp, sz, C.POINTER(vp)]),
+    "bp_ipa_begin_resident_powers": (ci, [vp, vp, ci, sz, sz, vp, vp, sz, C.POINTER(vp)]),
     "bp_ipa_scale_h": (ci, [vp, vp]),
     "bp_ipa_set_u": (ci, [vp, vp]),
     "bp_ipa_set_u_resident": (ci, [vp, sz, vp]),

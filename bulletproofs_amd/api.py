@@ -326,6 +326,11 @@ class Context:
     def ipa_begin_resident(self, bases, variant, g_offset, h_offset, a, b):
         return IpaSession(self, bases.curve, variant, None, None, a, b, resident=bases, g_offset=g_offset, h_offset=h_offset)
 
+    def ipa_begin_resident_powers(self, bases, variant, g_offset, h_offset, a, x):
+        """as ipa_begin_resident with b = (1, x, x^2, ...) built on the device"""
+        return IpaSession(self, bases.curve, variant, None, None, a, None, resident=bases, g_offset=g_offset,
+                          h_offset=h_offset, b_power=x)
+
 
 class Bases:
     """Device-resident base points (bp_bases): the CRS uploaded once."""
@@ -410,7 +415,15 @@ class IpaSession:
     """Device-resident G, H, a, b across the rounds of ipa::prove
     (src/ipa/mod.rs:33-95) or poly_commit::prove (src/poly_commit/mod.rs:69-105)."""
 
-    def __init__(self, ctx: Context, curve, variant, gs, hs, a, b, resident=None, g_offset=0, h_offset=0):
+    def __init__(self, ctx: Context, curve, variant, gs, hs, a, b, resident=None, g_offset=0, h_offset=0, b_power=None):
+        if resident is not None and b_power is not None:
+            # b_i = b_power^i built on the device (bp_ipa_begin_resident_powers; src/poly_commit/mod.rs:65)
+            a, x = _f(a), _f(b_power)
+            h = C.c_void_p()
+            ctx._chk(lib.bp_ipa_begin_resident_powers(ctx.h, resident.h, variant, g_offset, h_offset, _p(a), _p(x),
+                                                      a.shape[0], C.byref(h)))
+            self.ctx, self.h, self.has_h, self._bases = ctx, h, variant == 0, resident
+            return
         a, b = _f(a), _f(b)
         n = a.shape[0]
         if resident is not None:

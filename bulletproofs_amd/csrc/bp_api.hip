@@ -1368,7 +1368,10 @@ void ipa_release_block(bp_ctx* ctx, void* block, size_t cap) {
 int ipa_begin_common(bp_ctx* ctx, int curve, int variant, const bp_bases* res, size_t g_off, size_t h_off,
                      const uint64_t* gx, const uint64_t* gy, const uint8_t* ginf, const uint64_t* hx,
                      const uint64_t* hy, const uint8_t* hinf, const uint64_t* a, const uint64_t* b, size_t n,
-                     bp_ipa** out) {
+                     bp_ipa** out, const uint64_t* b_power = nullptr) {
+  // b == nullptr: b_i = b_power^i, built on the device
+  void* pow_tab = nullptr;
+  if (!b) CHK(reserve(ctx, S_TABLE, powers_table_elems(n) * 32, &pow_tab));
   bp_ipa* s = new (std::nothrow) bp_ipa();
   if (!s) return fail(ctx, BP_E_OOM, "host allocation");
   s->ctx = ctx;
@@ -1416,7 +1419,11 @@ int ipa_begin_common(bp_ctx* ctx, int curve, int variant, const bp_bases* res, s
       if (e == hipSuccess) e = hinf ? hipMemcpyAsync(dhi, hinf, n, hipMemcpyHostToDevice, ctx->stream) : hipMemsetAsync(dhi, 0, n, ctx->stream);
     }
   }
-  put(s->a, a, n * 32); put(s->b, b, n * 32);
+  put(s->a, a, n * 32);
+  if (b)
+    put(s->b, b, n * 32);
+  else if (e == hipSuccess)
+    e = launch_powers(curve, to_arg(b_power), n, (u32*)pow_tab, s->b, ctx->stream);
   if (e == hipSuccess) e = launch_fill_one(curve, s->cg, n, ctx->stream);
   if (e == hipSuccess && has_h) e = launch_fill_one(curve, s->ch, n, ctx->stream);
   // the host arrays may be reused by the caller as soon as this returns
@@ -1558,6 +1565,22 @@ int bp_ipa_begin_resident(bp_ctx* ctx, const bp_bases* bases, int variant, size_
   Guard g(ctx);
   return ipa_begin_common(ctx, bases->curve, variant, bases, g_offset, h_offset, nullptr, nullptr, nullptr, nullptr,
                           nullptr, nullptr, a, b, n, out);
+}
+
+int bp_ipa_begin_resident_powers(bp_ctx* ctx, const bp_bases* bases, int variant, size_t g_offset, size_t h_offset,
+                                 const uint64_t* a, const uint64_t x[4], size_t n, bp_ipa** out) {
+  if (!ctx || !out || !bases || !a || !x) return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident_powers: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident_powers: bases belong to another context");
+  if (variant != BP_IPA_BULLETPROOF && variant != BP_IPA_POLYCOMMIT)
+    return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident_powers: bad variant");
+  if (n == 0 || (n & (n - 1))) return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident_powers: n must be a power of two");
+  if (g_offset > bases->n || n > bases->n - g_offset)
+    return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident_powers: g range out of bounds");
+  if (variant == BP_IPA_BULLETPROOF && (h_offset > bases->n || n > bases->n - h_offset))
+    return fail(ctx, BP_E_ARG, "bp_ipa_begin_resident_powers: h range out of bounds");
+  Guard g(ctx);
+  return ipa_begin_common(ctx, bases->curve, variant, bases, g_offset, h_offset, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, a, nullptr, n, out, x);
 }
 
 int bp_ipa_scale_h(bp_ipa* s, const uint64_t* scale) {

@@ -79,11 +79,11 @@ struct PolyCommit {
     const size_t n = crs.gs.size();
     coeffs.resize(n, S::zero());
     Affine u = P::to_affine(P::lower(crs.gen_tab.mul(t.verifier_scalar())));             // :55-58
-    std::vector<Scalar> b(n);
-    check(ctx, bp_powers(ctx, CURVE, st.x.l, n, b[0].l), "bp_powers");                   // :65
+    // b = powers_of_x(x) (:65) is built where the session keeps it: no 32 bytes per coefficient
+    // down to the host and up again
     bp_ipa* s = nullptr;
-    check(ctx, bp_ipa_begin_resident(ctx, crs.bases, BP_IPA_POLYCOMMIT, 0, 0, coeffs[0].l, b[0].l, n, &s),
-          "bp_ipa_begin_resident");
+    check(ctx, bp_ipa_begin_resident_powers(ctx, crs.bases, BP_IPA_POLYCOMMIT, 0, 0, coeffs[0].l, st.x.l, n, &s),
+          "bp_ipa_begin_resident_powers");
     Todo todo;
     HXyzz ux = P::lift(u);
     try {

@@ -324,6 +324,13 @@ int bp_ipa_begin(bp_ctx* ctx, int curve, int variant, const uint64_t* gx, const 
 int bp_ipa_begin_resident(bp_ctx* ctx, const bp_bases* bases, int variant, size_t g_offset,
                           size_t h_offset, const uint64_t* a, const uint64_t* b, size_t n,
                           bp_ipa** out);
+/* As bp_ipa_begin_resident with b_i = x^i (i < n) built on the device: the
+ * `powers_of_x(statement.x).take(n)` that src/poly_commit/mod.rs:65 collects before the round
+ * loop, which the caller would otherwise compute, download and upload again (32 bytes per
+ * coefficient each way). */
+int bp_ipa_begin_resident_powers(bp_ctx* ctx, const bp_bases* bases, int variant, size_t g_offset,
+                                 size_t h_offset, const uint64_t* a, const uint64_t x[4], size_t n,
+                                 bp_ipa** out);
 /* From now on the session behaves as if H_i had been scale[i] * H_i (n host scalars):
  * the hs' = y^-i * h_i that src/range/aggregate.rs:148-153 materialises with n scalar
  * multiplications (create_hs_prime, src/range/utils.rs:22-29) before ipa::extended::prove.

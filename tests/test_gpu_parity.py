@@ -839,3 +839,31 @@ def test_window_tables_on_a_fresh_context(coracle, n):
         b.free()
     finally:
         fresh.close()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("n", [1, 8, 1024])
+def test_ipa_session_with_powers_built_on_the_device(ctx, c, n):
+    """bp_ipa_begin_resident_powers: b_i = x^i (src/poly_commit/mod.rs:65) built on the device gives the
+    same rounds as the session that was handed the powers: first L, R, c_l, c_r against the oracle, and
+    the vector b itself read back after one fold (at n = 1: as given)"""
+    import bulletproofs_amd as bp
+
+    g, _, a, _, ch = ipa_inputs(c, n, 77 + n)
+    x = 0xDEADBEEFCAFEF00D123456789ABCDEF0FEDCBA9876543210 % c.n
+    b = [pow(x, i, c.n) for i in range(n)]
+    bases = ctx.register_bases(c.id, o.pack_points(g, c))
+    s = ctx.ipa_begin_resident_powers(bases, bp.IPA_POLYCOMMIT, 0, 0, o.pack_field(a, c.n), o.pack_field([x], c.n))
+    if n > 1:
+        L, R, cl, cr = s.round_lr()
+        eL, eR, ecl, ecr = o.ipa_round_lr(1, g, g, a, b, c)
+        assert xyz_to_affine(L, c) == eL and xyz_to_affine(R, c) == eR
+        assert o.unpack_field(cl, c.n)[0] == ecl and o.unpack_field(cr, c.n)[0] == ecr
+        s.round_fold(o.pack_field([ch[0]], c.n), o.pack_field([pow(ch[0], -1, c.n)], c.n))
+        _, _, a2, b2 = o.ipa_round_fold(1, g, g, a, b, ch[0], c)
+    else:
+        a2, b2 = a, b
+    if n <= 8:
+        _, _, A, B = s.read()
+        assert o.unpack_field(A, c.n) == a2 and o.unpack_field(B, c.n) == b2
+    s.free()
