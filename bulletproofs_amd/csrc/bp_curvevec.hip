@@ -2,6 +2,7 @@
 // normalisation.  One thread owns one output point; the double-and-add schedule
 // of the generator fold is shared by all lanes (the two scalars are the same for
 // every output), so there is no divergence on the common path.
+#include <cstdlib>
 #include "bp_curve.h"
 #include "bp_internal.h"
 #include "bp_quad.h"
@@ -228,25 +229,57 @@ __global__ __launch_bounds__(256) void k_rebase_windows(RebaseJob job, size_t n,
   const u32* __restrict__ gy = job.gy[set];
   const uint8_t* __restrict__ ginf = job.ginf[set];
   const int8_t* __restrict__ digits = job.digits[set];
-  Xyzz b1 = xyzz_identity<F>(), b2 = b1, b3 = b1, b4 = b1;
+  // The four bucket sums live in four register slots; the bucket a step adds to is first swapped
+  // into slot 0 (the digit is the same for the whole block, so which slot holds which bucket is
+  // scalar state and the swap a uniform branch), and ONE inlined mixed addition works on slot 0.
+  // With an addition per bucket the loop body was four copies of it, 0.4 MB of code against a
+  // 64 KiB instruction cache.
+  Xyzz s0 = xyzz_identity<F>(), s1 = s0, s2 = s0, s3 = s0;
+  int at0 = 1, at1 = 2, at2 = 3, at3 = 4;  // bucket held by each slot
+  auto swap_slots = [](Xyzz& a, Xyzz& b) {
+    const Xyzz tmp = a;
+    a = b;
+    b = tmp;
+  };
   for (size_t t = 0; t < m; t++) {
     const int d = digits[t * kRebaseWindows + w];  // the same for every lane of the block
     if (d == 0) continue;
     const size_t k = i + n * t;
+    const int a = d < 0 ? -d : d;
+    if (at1 == a) {
+      swap_slots(s0, s1);
+      at1 = at0;
+      at0 = a;
+    } else if (at2 == a) {
+      swap_slots(s0, s2);
+      at2 = at0;
+      at0 = a;
+    } else if (at3 == a) {
+      swap_slots(s0, s3);
+      at3 = at0;
+      at0 = a;
+    }
     if (ginf && ginf[k]) continue;
     const Fe x = fe_import<P>(fe_load(gx + k * 8));
     Fe y = fe_import<P>(fe_load(gy + k * 8));
     if (d < 0) y = fe_neg<F>(y);
-    const int a = d < 0 ? -d : d;
-    if (a == 1)
-      xyzz_madd<F>(b1, x, y);
-    else if (a == 2)
-      xyzz_madd<F>(b2, x, y);
-    else if (a == 3)
-      xyzz_madd<F>(b3, x, y);
-    else
-      xyzz_madd<F>(b4, x, y);
+    xyzz_madd<F>(s0, x, y);
   }
+  // back to the buckets by number: a sorting network over the four slots (uniform branches again)
+  auto order = [&](Xyzz& a, int& ka, Xyzz& b, int& kb) {
+    if (ka > kb) {
+      swap_slots(a, b);
+      const int k = ka;
+      ka = kb;
+      kb = k;
+    }
+  };
+  order(s0, at0, s1, at1);
+  order(s2, at2, s3, at3);
+  order(s0, at0, s2, at2);
+  order(s1, at1, s3, at3);
+  order(s1, at1, s2, at2);
+  const Xyzz &b1 = s0, &b2 = s1, &b3 = s2, &b4 = s3;
   // b1 + 2 b2 + 3 b3 + 4 b4 by running sums
   Xyzz run = b4, sum = b4;
   xyzz_add<F>(run, b3);
@@ -311,6 +344,42 @@ __global__ __launch_bounds__(256) void k_rebase_finish(RebaseJob job, size_t n, 
   }
 }
 
+// The same combination with one lane per output, for launches that fill the machine with lanes
+// anyway: a quad finishes one output in half the time but issues 2.2 times the instructions, which
+// pays only while SIMDs would otherwise idle (65 536 outputs: 3.3 ms on quads, a chain of about
+// 3 500 dependent multiplications per lane at one wave per SIMD here).
+template <class C>
+__global__ __launch_bounds__(256) void k_rebase_finish_lane(RebaseJob job, size_t n, int sets) {
+  using P = typename C::Pipeline;
+  using F = typename P::Fq;
+  const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n * (size_t)sets) return;
+  const int set = (int)(o / n);
+  const size_t i = o % n;
+  const u32* __restrict__ win = job.win[set];
+  Xyzz acc = xyzz_identity<F>();
+#pragma unroll 1
+  for (int w = kRebaseWindows - 1; w >= 0; w--) {
+#pragma unroll 1
+    for (int k = 0; k < kRebaseBits; k++) acc = xyzz_dbl<F>(acc);
+    const u32* src = win + ((size_t)w * n + i) * 32;
+    Xyzz v;
+    v.x = fe_load(src);
+    v.y = fe_load(src + 8);
+    v.zz = fe_load(src + 16);
+    v.zzz = fe_load(src + 24);
+    xyzz_add<F>(acc, v);
+  }
+  Fe x, y;
+  const bool inf = xyzz_to_affine<F>(acc, x, y);
+  fe_store(job.ox[set] + i * 8, inf ? x : fe_export<P>(x));
+  fe_store(job.oy[set] + i * 8, inf ? y : fe_export<P>(y));
+  job.oinf[set][i] = inf ? 1 : 0;
+}
+
+// outputs from which the combination runs one lane per output (about a wave per SIMD)
+constexpr size_t kRebaseLaneFinishMin = 32768;
+
 hipError_t launch_ipa_rebase(int curve, const RebaseSet* sets, int n_sets, size_t n, size_t m, hipStream_t st) {
   if (n == 0 || m == 0 || n_sets < 1 || n_sets > 2) return hipErrorInvalidValue;
   RebaseJob job{};
@@ -322,7 +391,11 @@ hipError_t launch_ipa_rebase(int curve, const RebaseSet* sets, int n_sets, size_
   const unsigned fb = (unsigned)((n * (size_t)n_sets + 63) / 64);
   DISPATCH_CURVE(curve, {
     hipLaunchKernelGGL(k_rebase_windows<C>, dim3(bx, kRebaseWindows, (unsigned)n_sets), dim3(256), 0, st, job, n, m);
-    hipLaunchKernelGGL(k_rebase_finish<C>, dim3(fb), dim3(256), 0, st, job, n, n_sets);
+    if (n * (size_t)n_sets >= kRebaseLaneFinishMin && !getenv("BP_REBASE_QUAD_FINISH"))
+      hipLaunchKernelGGL(k_rebase_finish_lane<C>, dim3((unsigned)((n * (size_t)n_sets + 255) / 256)), dim3(256), 0, st,
+                         job, n, n_sets);
+    else
+      hipLaunchKernelGGL(k_rebase_finish<C>, dim3(fb), dim3(256), 0, st, job, n, n_sets);
   });
   return hipGetLastError();
 }

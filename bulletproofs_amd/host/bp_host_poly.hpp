@@ -59,9 +59,12 @@ struct PolyCommit {
   }
 
   // Witness::statement, src/poly_commit/types.rs:137-151; coeffs are zero-padded to the CRS size
-  static Statement statement(bp_ctx* ctx, const Crs& crs, std::vector<Scalar> coeffs, const Scalar& r, const Scalar& x) {
+  static Statement statement(bp_ctx* ctx, const Crs& crs, const std::vector<Scalar>& coeffs_in, const Scalar& r,
+                             const Scalar& x) {
     const size_t n = crs.gs.size();
-    coeffs.resize(n, S::zero());
+    std::vector<Scalar> padded;
+    if (coeffs_in.size() != n) { padded = coeffs_in; padded.resize(n, S::zero()); }
+    const std::vector<Scalar>& coeffs = padded.empty() ? coeffs_in : padded;
     Statement st;
     st.x = x;
     Projective g;
@@ -74,16 +77,23 @@ struct PolyCommit {
   }
 
   // poly_commit::prove, src/poly_commit/mod.rs:45-119
-  static Todo prove(bp_ctx* ctx, const Crs& crs, const Statement& st, std::vector<Scalar> coeffs, Scalar r, Transcript& t,
-                    RandomSource& rng, PolyProof& proof) {
+  static Todo prove(bp_ctx* ctx, const Crs& crs, const Statement& st, const std::vector<Scalar>& coeffs_in, Scalar r,
+                    Transcript& t, RandomSource& rng, PolyProof& proof) {
+    PhaseTrace trace;
     const size_t n = crs.gs.size();
-    coeffs.resize(n, S::zero());
+    // zero-padded to the CRS size (:61-64); a polynomial that already has that many coefficients is
+    // read where it lies (a copy of 2^20 coefficients costs 7 ms of page faults and memcpy)
+    std::vector<Scalar> padded;
+    if (coeffs_in.size() != n) { padded = coeffs_in; padded.resize(n, S::zero()); }
+    const std::vector<Scalar>& coeffs = padded.empty() ? coeffs_in : padded;
     Affine u = P::to_affine(P::lower(crs.gen_tab.mul(t.verifier_scalar())));             // :55-58
+    trace.mark("padding, u");
     // b = powers_of_x(x) (:65) is built where the session keeps it: no 32 bytes per coefficient
     // down to the host and up again
     bp_ipa* s = nullptr;
     check(ctx, bp_ipa_begin_resident_powers(ctx, crs.bases, BP_IPA_POLYCOMMIT, 0, 0, coeffs[0].l, st.x.l, n, &s),
           "bp_ipa_begin_resident_powers");
+    trace.mark("session begin");
     Todo todo;
     HXyzz ux = P::lift(u);
     try {
@@ -109,13 +119,16 @@ struct PolyCommit {
         r = S::add(r, S::add(S::mul(l_j, S::mul(u_j, u_j)), S::mul(r_j, S::mul(u_inv, u_inv))));  // :104
         proof.L.push_back(lr[0]); proof.R.push_back(lr[1]);
       }
+      trace.mark("rounds");
       // a[0] and the folded generator g[0]; the session computes g[0] as <s-vector, gs>,
       // which is the value the reference asserts it to equal (:108-113)
       uint8_t ginf = 0;
       check(ctx, bp_ipa_read(s, todo.g.x, todo.g.y, &ginf, nullptr, nullptr, nullptr, proof.a.l, nullptr), "bp_ipa_read");
       todo.g.inf = ginf;
+      trace.mark("final a, g");
     } catch (...) { bp_ipa_free(s); throw; }
     bp_ipa_free(s);
+    trace.mark("session free");
     proof.r = r;
     Scalar msg[2] = {proof.a, proof.r};
     t.prover_scalars(msg, 2);                                                           // :107

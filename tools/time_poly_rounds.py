@@ -38,8 +38,9 @@ u = np.concatenate([px[n], py[n]])
 ch = rand_field(logn)
 chi = ctx.batch_inversion(C, ch)
 for rep in range(2):
+    va, vb = rand_field(n), rand_field(n)
     t00 = time.perf_counter()
-    s = ctx.ipa_begin_resident(bases, bp.IPA_POLYCOMMIT, 0, 0, rand_field(n), rand_field(n))
+    s = ctx.ipa_begin_resident(bases, bp.IPA_POLYCOMMIT, 0, 0, va, vb)
     s.set_u(u)
     t_begin = time.perf_counter() - t00
     t_lr, t_fold = [], []
