@@ -20,6 +20,7 @@ from ._lib import lib
 SECP256K1, VESTA = 0, 1
 VEC_ADD, VEC_SUB, VEC_HADAMARD, VEC_SCALE, VEC_AXPY = 0, 1, 2, 3, 4
 IPA_BULLETPROOF, IPA_POLYCOMMIT = 0, 1
+POINT_WIRE_BYTES = 33  # ark-serialize, Compress::Yes, on both curves
 
 
 class BpError(RuntimeError):
@@ -295,6 +296,25 @@ class Context:
         oi = np.zeros(n, dtype=np.uint8)
         self._chk(lib.bp_scale_points(self.h, curve, _p(px), _p(py), _p(pi), _p(s), n, _p(ox), _p(oy), _p(oi)))
         return ox, oy, oi
+
+    def points_compress(self, curve, points):
+        """ark-serialize's compressed encoding of affine points: (n, 33) bytes (bp_points_compress)"""
+        px, py, pi = _pts(points)
+        n = px.shape[0]
+        out = np.zeros((n, POINT_WIRE_BYTES), dtype=np.uint8)
+        self._chk(lib.bp_points_compress(self.h, curve, _p(px), _p(py), _p(pi), n, _p(out)))
+        return out
+
+    def points_decompress(self, curve, data):
+        """(n, 33) bytes -> (x, y, inf), ok: y recomputed on the device; ok[i] = 0 where the bytes are no point"""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, POINT_WIRE_BYTES)
+        n = data.shape[0]
+        ox = np.zeros((n, 4), dtype=np.uint64)
+        oy = np.zeros((n, 4), dtype=np.uint64)
+        oi = np.zeros(n, dtype=np.uint8)
+        ok = np.zeros(n, dtype=np.uint8)
+        self._chk(lib.bp_points_decompress(self.h, curve, _p(data), n, _p(ox), _p(oy), _p(oi), _p(ok)))
+        return (ox, oy, oi), ok
 
     def normalize_batch(self, curve, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.uint64).reshape(-1, 12)

@@ -1283,6 +1283,49 @@ int bp_scale_points(bp_ctx* ctx, int curve, const uint64_t* px, const uint64_t* 
   return BP_OK;
 }
 
+int bp_points_compress(bp_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py, const uint8_t* pinf, size_t n,
+                       uint8_t* out) {
+  if (!ctx || (n && (!px || !py || !out))) return fail(ctx, BP_E_ARG, "bp_points_compress: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) return BP_OK;
+  void *dx, *dy, *di = nullptr, *dout;
+  CHK(upload(ctx, S_IN0, px, n * 32, &dx));
+  CHK(upload(ctx, S_IN1, py, n * 32, &dy));
+  if (pinf) CHK(upload(ctx, S_IN2, pinf, n, &di));
+  CHK(reserve(ctx, S_OUT0, n * BP_POINT_WIRE_BYTES, &dout));
+  hipError_t e = launch_points_compress(curve, (const u32*)dx, (const u32*)dy, (const uint8_t*)di, n, (uint8_t*)dout,
+                                        ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "points_compress", e);
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, n * BP_POINT_WIRE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_points_decompress(bp_ctx* ctx, int curve, const uint8_t* in, size_t n, uint64_t* out_x, uint64_t* out_y,
+                         uint8_t* out_inf, uint8_t* out_ok) {
+  if (!ctx || (n && (!in || !out_x || !out_y || !out_inf || !out_ok)))
+    return fail(ctx, BP_E_ARG, "bp_points_decompress: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) return BP_OK;
+  void *din, *dox, *doy, *doi, *dok;
+  CHK(upload(ctx, S_IN0, in, n * BP_POINT_WIRE_BYTES, &din));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dox));
+  CHK(reserve(ctx, S_OUT1, n * 32, &doy));
+  CHK(reserve(ctx, S_OUT2, n, &doi));
+  CHK(reserve(ctx, S_IN1, n, &dok));
+  hipError_t e = launch_points_decompress(curve, (const uint8_t*)din, n, (u32*)dox, (u32*)doy, (uint8_t*)doi,
+                                          (uint8_t*)dok, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "points_decompress", e);
+  HIPCHK(ctx, hipMemcpyAsync(out_x, dox, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out_y, doy, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out_inf, doi, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out_ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
 int bp_normalize_batch(bp_ctx* ctx, int curve, const uint64_t* xyz, size_t n, uint64_t* out_x, uint64_t* out_y,
                        uint8_t* out_inf) {
   if (!ctx || (n && (!xyz || !out_x || !out_y))) return fail(ctx, BP_E_ARG, "bp_normalize_batch: null argument");

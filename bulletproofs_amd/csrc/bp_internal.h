@@ -35,6 +35,11 @@ hipError_t launch_s_vector_axpy(int curve, const u32* ch, const u32* ch_inv, int
                                 u32* acc, hipStream_t st);
 size_t s_vector_table_elems(int k);
 // table: >= (256 + ceil(n/256)) * 8 u32
+// compressed point encoding of ark-serialize (33 bytes per point), bp_wire.hip
+hipError_t launch_points_compress(int curve, const u32* x, const u32* y, const uint8_t* inf, size_t n, uint8_t* out,
+                                  hipStream_t st);
+hipError_t launch_points_decompress(int curve, const uint8_t* in, size_t n, u32* x, u32* y, uint8_t* inf, uint8_t* ok,
+                                    hipStream_t st);
 hipError_t launch_powers(int curve, FeArg x, size_t n, u32* table, u32* out, hipStream_t st);
 size_t powers_table_elems(size_t n);
 hipError_t launch_batch_inverse(int curve, int field, u32* v, size_t n, hipStream_t st);

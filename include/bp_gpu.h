@@ -272,6 +272,19 @@ int bp_fold_generators(bp_ctx* ctx, int curve, const uint64_t* lx, const uint64_
 int bp_scale_points(bp_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py,
                     const uint8_t* pinf, const uint64_t* s, size_t n, uint64_t* out_x,
                     uint64_t* out_y, uint8_t* out_inf);
+/* Wire format of points: the compressed encoding the reference's proof and CRS types get from
+ * ark-serialize 0.5 (CanonicalSerialize, Compress::Yes, behind the Encoding / NargDeserialize
+ * derives: src/ipa/types.rs:48,140; prover_messages at src/ipa/mod.rs:75,97).  33 bytes per point on
+ * both curves: the canonical x in 32 little-endian bytes, then a flag byte (bit 7: y > p - y, bit 6:
+ * the identity, written with x = 0).  bp_points_compress writes n * 33 bytes.
+ * bp_points_decompress recomputes y = sqrt(x^3 + b) on the device (the smaller root unless bit 7 is
+ * set) and sets out_ok[i] = 0 where the bytes are no point (x >= p, both flags, no square root; x, y
+ * are then 0).  The reference holds no byte vector of this encoding: it restates the published format. */
+#define BP_POINT_WIRE_BYTES 33
+int bp_points_compress(bp_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py,
+                       const uint8_t* pinf, size_t n, uint8_t* out);
+int bp_points_decompress(bp_ctx* ctx, int curve, const uint8_t* in, size_t n, uint64_t* out_x,
+                         uint64_t* out_y, uint8_t* out_inf, uint8_t* out_ok);
 /* Jacobian (n*12 u64) -> affine: G::normalize_batch at src/ipa/mod.rs:187,226,
  * src/range/aggregate.rs:223. */
 int bp_normalize_batch(bp_ctx* ctx, int curve, const uint64_t* xyz, size_t n, uint64_t* out_x,

@@ -773,3 +773,55 @@ def fold_todos(c: Curve, todos, alpha, x):
         evaluation = (evaluation + ai * hpoly_evaluate(ui, x, mod)) % mod
         ai = ai * alpha % mod
     return coeffs, commitment, evaluation
+
+
+# ---- wire format of points (ark-serialize 0.5, Compress::Yes) ------------------------------------
+# Not in the reference tree: the proof and CRS types derive their encoding from the arkworks crates
+# (src/ipa/types.rs:48,140).  Restated from the published format; no reference byte vector pins it.
+
+def field_sqrt(a, p):
+    """a square root of a mod p, or None (Tonelli-Shanks; p = 3 mod 4 takes the short cut)"""
+    a %= p
+    if a == 0:
+        return 0
+    if pow(a, (p - 1) // 2, p) != 1:
+        return None
+    if p % 4 == 3:
+        return pow(a, (p + 1) // 4, p)
+    s, t = 0, p - 1
+    while t % 2 == 0:
+        s, t = s + 1, t // 2
+    g = 2
+    while pow(g, (p - 1) // 2, p) != p - 1:
+        g += 1
+    z, x, b, v = pow(g, t, p), pow(a, (t + 1) // 2, p), pow(a, t, p), s
+    while b != 1:
+        k, b2 = 0, b
+        while b2 != 1:
+            b2, k = b2 * b2 % p, k + 1
+        w = pow(z, 1 << (v - k - 1), p)
+        z, b, x, v = w * w % p, b * w * w % p, x * w % p, k
+    return x
+
+
+def point_compress(P, c):
+    """33 bytes: x little-endian, flag byte (0x80: y > p - y; 0x40: the identity, x = 0)"""
+    if P is None:
+        return bytes(32) + b"\x40"
+    x, y = P
+    return x.to_bytes(32, "little") + (b"\x80" if y > (c.p - y) % c.p else b"\x00")
+
+
+def point_decompress(data, c):
+    """-> (ok, point): the smaller root unless bit 7 is set; x >= p, both flags or a non-residue fail"""
+    x, flags = int.from_bytes(data[:32], "little"), data[32]
+    neg, inf = bool(flags & 0x80), bool(flags & 0x40)
+    if x >= c.p or (neg and inf):
+        return False, None
+    if inf:
+        return True, None
+    y = field_sqrt((x * x * x + c.b) % c.p, c.p)
+    if y is None:
+        return False, None
+    small, large = min(y, c.p - y), max(y, c.p - y)
+    return True, (x, large if neg else small)

@@ -1,0 +1,109 @@
+"""Wire format of points (ark-serialize 0.5 compressed encoding, 33 bytes on both curves).
+CPU: the Python restatement against values that can be written down by hand (the secp256k1
+generator of SEC 2, whose y is the smaller root; the identity; the square-root routine on both base
+fields).  GPU: bp_points_compress / bp_points_decompress against that restatement, bit-exact,
+including the identity, both signs of y, and bytes that are no point.  The reference holds no byte
+vector of this encoding (its types derive it from the arkworks crates), so parity with arkworks
+itself is unpinned; what is pinned is the format as published and the algebra (y^2 = x^3 + b)."""
+import numpy as np
+import pytest
+
+import bp_oracle as o
+
+CURVES = [o.SECP256K1, o.VESTA]
+ids = lambda c: c.name  # noqa: E731
+
+
+def sample_points(c, n, seed):
+    rng = o.SplitMix64(seed)
+    return o.gen_points_arith(n, rng.field(c.n), rng.field(c.n), c)
+
+
+def test_generator_bytes():
+    c = o.SECP256K1
+    data = o.point_compress(c.g, c)
+    assert len(data) == 33
+    assert data[:32] == bytes.fromhex("79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798")[::-1]
+    assert data[32] == 0x00  # Gy = 0x483A... is below p/2: the "positive" root
+    neg = (c.g[0], c.p - c.g[1])
+    assert o.point_compress(neg, c)[32] == 0x80
+    assert o.point_compress(None, c) == bytes(32) + b"\x40"
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_sqrt_and_round_trip(c):
+    rng = o.SplitMix64(0x5152 + c.id)
+    for _ in range(40):
+        a = rng.field(c.p)
+        r = o.field_sqrt(a * a % c.p, c.p)
+        assert r in (a, c.p - a)
+    non_residues = [a for a in range(2, 40) if pow(a, (c.p - 1) // 2, c.p) == c.p - 1]
+    assert non_residues and all(o.field_sqrt(a, c.p) is None for a in non_residues)
+    for P in sample_points(c, 24, 0x77 + c.id) + [None, c.g, (c.g[0], c.p - c.g[1])]:
+        ok, Q = o.point_decompress(o.point_compress(P, c), c)
+        assert ok and Q == P
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_rejections(c):
+    good = bytearray(o.point_compress(c.g, c))
+    both = bytes(good[:32]) + b"\xc0"
+    assert o.point_decompress(both, c) == (False, None)
+    too_big = c.p.to_bytes(32, "little") + b"\x00"
+    assert o.point_decompress(too_big, c) == (False, None)
+    x = 1
+    while o.field_sqrt((x ** 3 + c.b) % c.p, c.p) is not None:
+        x += 1
+    assert o.point_decompress(x.to_bytes(32, "little") + b"\x00", c) == (False, None)
+    # the six low bits of the flag byte are not part of the integer
+    noisy = bytes(good[:32]) + bytes([good[32] | 0x2A])
+    assert o.point_decompress(noisy, c) == (True, c.g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("n", [1, 5, 300, 4099])
+def test_gpu_compress_and_decompress(ctx, c, n):
+    pts = sample_points(c, n, 0x9000 + n + c.id)
+    # both signs of y, the identity, the generator
+    pts = [(P[0], c.p - P[1]) if i % 3 == 1 else P for i, P in enumerate(pts)]
+    if n >= 5:
+        pts[2] = None
+        pts[4] = c.g
+    X, Y, INF = o.pack_points(pts, c)
+    got = ctx.points_compress(c.id, (X, Y, INF))
+    expect = np.frombuffer(b"".join(o.point_compress(P, c) for P in pts), dtype=np.uint8).reshape(n, 33)
+    assert np.array_equal(got, expect)
+    (x2, y2, inf2), ok = ctx.points_decompress(c.id, got)
+    assert ok.all()
+    assert o.unpack_points(x2, y2, inf2, c) == pts
+    assert np.array_equal(x2, X) and np.array_equal(y2, Y) and np.array_equal(inf2, INF)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_gpu_decompress_rejects_what_is_no_point(ctx, c):
+    rows, expect_ok = [], []
+    g = o.point_compress(c.g, c)
+    rows.append(g); expect_ok.append(1)
+    rows.append(g[:32] + b"\xc0"); expect_ok.append(0)                        # both flags
+    rows.append(c.p.to_bytes(32, "little") + b"\x00"); expect_ok.append(0)    # x = p
+    rows.append(((1 << 256) - 1).to_bytes(32, "little") + b"\x80"); expect_ok.append(0)
+    x = 1
+    while o.field_sqrt((x ** 3 + c.b) % c.p, c.p) is not None:
+        x += 1
+    rows.append(x.to_bytes(32, "little") + b"\x00"); expect_ok.append(0)      # x^3 + b is no square
+    rows.append(g[:32] + bytes([g[32] | 0x15])); expect_ok.append(1)          # low bits of the flag byte ignored
+    rows.append(bytes(32) + b"\x40"); expect_ok.append(1)                     # the identity
+    for xx in range(1, 12):                                                   # small x either way
+        ok, _ = o.point_decompress(xx.to_bytes(32, "little") + b"\x80", c)
+        rows.append(xx.to_bytes(32, "little") + b"\x80"); expect_ok.append(1 if ok else 0)
+    data = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), 33)
+    (x2, y2, inf2), ok = ctx.points_decompress(c.id, data)
+    assert ok.tolist() == expect_ok
+    pts = o.unpack_points(x2, y2, inf2, c)
+    for row, good, P in zip(rows, expect_ok, pts):
+        if good:
+            assert (True, P) == o.point_decompress(row, c)
+        else:
+            assert P == (0, 0) or P is None
