@@ -199,3 +199,17 @@ for _ in range(3):
 print(json.dumps({"kernel": "ipa_verify", "n": n, "msm_points": 2 * n + 34, "total_ms": min(ts) * 1e3,
                   "verifies_per_s": 1 / min(ts)}), flush=True)
 bases.free()
+
+# ---- points from bytes: a CRS of 2^20 compressed points decoded into a base set (host bytes in) ----
+n = 1 << 20
+wx, wy = gen_points(1 << 16)
+wire = np.tile(ctx.points_compress(C, (wx, wy, None)), (n >> 16, 1))
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    wb = ctx.register_bases_compressed(C, wire)
+    ts.append(time.perf_counter() - t0)
+    wb.free()
+print(json.dumps({"kernel": "bases_register_compressed", "n": n, "total_ms": min(ts) * 1e3, "points_per_s": n / min(ts),
+                  "note": "33 bytes per point uploaded, one square root (a^((p+1)/4)) per point on the device, base set allocated"}),
+      flush=True)

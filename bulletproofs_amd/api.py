@@ -142,6 +142,10 @@ class Context:
     def register_bases(self, curve, bases):
         return Bases(self, curve, bases)
 
+    def register_bases_compressed(self, curve, data):
+        """base set from (n, 33) compressed points, decoded on the device (bp_bases_register_compressed)"""
+        return Bases(self, curve, None, compressed=data)
+
     def msm_windows_dev(self, curve, d_x, d_y, d_inf, d_s, n, d_windows):
         nw, cb = C.c_int(), C.c_int()
         self._chk(lib.bp_msm_windows_dev(self.h, curve, d_x, d_y, d_inf, d_s, n, d_windows, C.byref(nw), C.byref(cb)))
@@ -355,9 +359,12 @@ class Context:
 class Bases:
     """Device-resident base points (bp_bases): the CRS uploaded once."""
 
-    def __init__(self, ctx: Context, curve, bases, records=None):
+    def __init__(self, ctx: Context, curve, bases, records=None, compressed=None):
         h = C.c_void_p()
-        if records is not None:
+        if compressed is not None:
+            data = np.ascontiguousarray(compressed, dtype=np.uint8).reshape(-1, POINT_WIRE_BYTES)
+            ctx._chk(lib.bp_bases_register_compressed(ctx.h, curve, _p(data), data.shape[0], C.byref(h)))
+        elif records is not None:
             rec = np.ascontiguousarray(records, dtype=np.uint8)
             if rec.ndim != 2 or rec.shape[1] != AOS_STRIDE:
                 raise ValueError("records must be (n, 72) bytes")

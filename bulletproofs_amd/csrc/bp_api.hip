@@ -555,7 +555,7 @@ int bp_msm_aos(bp_ctx* ctx, int curve, const void* bases, const uint64_t* scalar
 
 namespace {
 int bases_register_impl(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, const uint8_t* inf, const void* aos,
-                        size_t n, bp_bases** out);
+                        size_t n, bp_bases** out, const uint8_t* wire = nullptr);
 }
 
 int bp_bases_register(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, const uint8_t* inf, size_t n,
@@ -574,7 +574,7 @@ int bp_bases_register_aos(bp_ctx* ctx, int curve, const void* bases, size_t n, b
 namespace {
 // planes (x, y, inf) or, when aos is given, n records of BP_AOS_STRIDE bytes split on the device
 int bases_register_impl(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t* y, const uint8_t* inf, const void* aos,
-                        size_t n, bp_bases** out) {
+                        size_t n, bp_bases** out, const uint8_t* wire) {
   Guard g(ctx);
   bp_bases* b = new (std::nothrow) bp_bases();
   if (!b) return fail(ctx, BP_E_OOM, "host allocation");
@@ -599,7 +599,23 @@ int bases_register_impl(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_
   if ((e = hipMalloc((void**)&b->x, bytes)) != hipSuccess || (e = hipMalloc((void**)&b->y, bytes)) != hipSuccess ||
       (e = hipMalloc((void**)&b->inf, n ? n : 1)) != hipSuccess)
     return fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "bp_bases_register: hipMalloc", e);
-  if (n && aos) {
+  if (n && wire) {
+    // compressed bytes: decoded straight into the base set; one flag per point comes back
+    void *raw, *dok;
+    CHK(upload(ctx, S_AOS, wire, n * BP_POINT_WIRE_BYTES, &raw));
+    CHK(reserve(ctx, S_IN1, n, &dok));
+    e = launch_points_decompress(curve, (const uint8_t*)raw, n, b->x, b->y, b->inf, (uint8_t*)dok, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "points_decompress", e);
+    std::vector<uint8_t> ok(n);
+    HIPCHK(ctx, hipMemcpyAsync(ok.data(), dok, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n; i++)
+      if (!ok[i]) {
+        char msg[96];
+        snprintf(msg, sizeof msg, "bp_bases_register_compressed: bytes of point %zu are no point", i);
+        return fail(ctx, BP_E_ARG, msg);
+      }
+  } else if (n && aos) {
     void* raw;
     CHK(upload(ctx, S_AOS, aos, n * BP_AOS_STRIDE, &raw));
     e = launch_aos_split((const u32*)raw, n, b->x, b->y, b->inf, ctx->stream);
@@ -619,6 +635,12 @@ int bases_register_impl(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_
   return BP_OK;
 }
 }  // namespace
+
+int bp_bases_register_compressed(bp_ctx* ctx, int curve, const uint8_t* bytes, size_t n, bp_bases** out) {
+  if (!ctx || !out || (n && !bytes)) return fail(ctx, BP_E_ARG, "bp_bases_register_compressed: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  return bases_register_impl(ctx, curve, nullptr, nullptr, nullptr, nullptr, n, out, bytes);
+}
 
 void bp_bases_free(bp_bases* b) {
   if (!b) return;

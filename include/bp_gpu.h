@@ -285,6 +285,11 @@ int bp_points_compress(bp_ctx* ctx, int curve, const uint64_t* px, const uint64_
                        const uint8_t* pinf, size_t n, uint8_t* out);
 int bp_points_decompress(bp_ctx* ctx, int curve, const uint8_t* in, size_t n, uint64_t* out_x,
                          uint64_t* out_y, uint8_t* out_inf, uint8_t* out_ok);
+/* bp_bases_register for a CRS that arrives as n compressed points (n * 33 bytes): decoded straight
+ * into the base set on the device.  BP_E_ARG (and no base set) if any element is no point; the
+ * message of bp_last_error names the first one. */
+int bp_bases_register_compressed(bp_ctx* ctx, int curve, const uint8_t* bytes, size_t n,
+                                 bp_bases** out);
 /* Jacobian (n*12 u64) -> affine: G::normalize_batch at src/ipa/mod.rs:187,226,
  * src/range/aggregate.rs:223. */
 int bp_normalize_batch(bp_ctx* ctx, int curve, const uint64_t* xyz, size_t n, uint64_t* out_x,

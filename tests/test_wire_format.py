@@ -107,3 +107,29 @@ def test_gpu_decompress_rejects_what_is_no_point(ctx, c):
             assert (True, P) == o.point_decompress(row, c)
         else:
             assert P == (0, 0) or P is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_gpu_base_set_from_compressed_points(ctx, c):
+    """bp_bases_register_compressed: an MSM over the decoded base set equals the oracle's over the points;
+    one bad element refuses the whole set and names it"""
+    from bulletproofs_amd.api import BpError
+    from util import xyz_to_affine
+
+    n = 200
+    pts = sample_points(c, n, 0xBA5E + c.id)
+    pts[7] = None
+    pts = [(P[0], c.p - P[1]) if P is not None and i % 2 else P for i, P in enumerate(pts)]
+    data = np.frombuffer(b"".join(o.point_compress(P, c) for P in pts), dtype=np.uint8).reshape(n, 33).copy()
+    rng = o.SplitMix64(0x5CA1 + c.id)
+    ks = rng.scalars(n, c.n)
+    bases = ctx.register_bases_compressed(c.id, data)
+    assert len(bases) == n
+    got = bases.msm(o.pack_field(ks, c.n))
+    assert xyz_to_affine(got, c) == o.msm_naive(pts, ks, c)
+    bases.free()
+    data[11, 32] = 0xC0
+    with pytest.raises(BpError) as err:
+        ctx.register_bases_compressed(c.id, data)
+    assert "point 11" in str(err.value)
