@@ -43,10 +43,10 @@ PEAK_PROBES = 6
 PEAK_PROBE_ITERS = 12000  # one probe launch runs >= 50 ms
 # Memory-side bytes of one k_chunk_sums launch at the default size, from separate
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script (averages over the
-# launches; profiles/r02_v4_pmc_summary.csv).  The counters read KiB; a
+# launches; profiles/r02_v5_pmc_summary.csv).  The counters read KiB; a
 # scattered read of 64-byte records with a known byte count (tools/calib_gather.py,
 # profiles/r01_gather64_calibration.csv) reads back exactly, so no factor is applied.
-PMC_TRAFFIC_2_20 = {"fetch_bytes": 1219014.1 * 1024, "write_bytes": 125875.0 * 1024}
+PMC_TRAFFIC_2_20 = {"fetch_bytes": 1220025.9 * 1024, "write_bytes": 125880.7 * 1024}
 CPU_MSM_SAMPLES = 5
 
 
