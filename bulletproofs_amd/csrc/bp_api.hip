@@ -8,6 +8,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -606,8 +607,9 @@ int bases_register_impl(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_
     CHK(reserve(ctx, S_IN1, n, &dok));
     e = launch_points_decompress(curve, (const uint8_t*)raw, n, b->x, b->y, b->inf, (uint8_t*)dok, ctx->stream);
     if (e != hipSuccess) return fail(ctx, BP_E_HIP, "points_decompress", e);
-    std::vector<uint8_t> ok(n);
-    HIPCHK(ctx, hipMemcpyAsync(ok.data(), dok, n, hipMemcpyDeviceToHost, ctx->stream));
+    std::unique_ptr<uint8_t[]> ok(new (std::nothrow) uint8_t[n]);
+    if (!ok) return fail(ctx, BP_E_OOM, "host allocation");
+    HIPCHK(ctx, hipMemcpyAsync(ok.get(), dok, n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < n; i++)
       if (!ok[i]) {
