@@ -90,6 +90,56 @@ def gen_points_on_gpu(ctx, n, rank):
     return ox, oy
 
 
+def other_configs(ctx, px, py):
+    """BASELINE configs 3 and 5 beside the headline figure, on the points of the MSM leg: the rounds of
+    an inner-product argument over 2 x 2^16 generators (benches/ipa_bench.rs:102-105, seeded challenges)
+    and a polynomial-commitment opening of degree 2^20 - 1 with its verification and the fold of two
+    deferred checks (benches/poly_commit_bench.rs), each through the C++ drivers / the session API."""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import host_mirror
+
+    C = bp.SECP256K1
+    rng = np.random.default_rng(SEED + 77)
+
+    def rand_field(cnt):
+        a = rng.integers(0, 1 << 64, (cnt, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 63) - 1)
+        return a
+
+    out = {}
+    n = 1 << 16
+    if px.shape[0] >= 2 * n:
+        ch = rand_field(16)
+        chi = ctx.batch_inversion(C, ch)
+        best = None
+        for _ in range(2):
+            s = ctx.ipa_begin(C, bp.IPA_BULLETPROOF, (px[:n], py[:n], None), (px[n:2 * n], py[n:2 * n], None), rand_field(n),
+                              rand_field(n))
+            t0 = time.perf_counter()
+            for j in range(16):
+                s.round_lr()
+                s.round_fold(ch[j:j + 1], chi[j:j + 1])
+            dt = time.perf_counter() - t0
+            s.free()
+            best = dt if best is None else min(best, dt)
+        out["ipa_2_16"] = {"workload": "inner-product argument, n = 2^16 (2 x 2^16 generators), 16 rounds, seeded challenges",
+                           "prove_rounds_ms": best * 1e3, "proofs_per_s": 1.0 / best}
+    n = px.shape[0]
+    if n >= 1 << 20:
+        n = 1 << 20
+        # CRS: the MSM leg's points; h and the generator of u: two more multiples of G
+        hx, hy, _ = ctx.scale_points(C, (px[:2], py[:2], None), rand_field(2))
+        hg = np.stack([np.concatenate([hx[0], hy[0]]), np.concatenate([hx[1], hy[1]])])
+        gs = (px[:n], py[:n], None)
+        coeffs, r, x = rand_field(n), rand_field(1), rand_field(1)
+        host_mirror.poly_commit_roundtrip(ctx, C, gs, hg, coeffs, r, x, SEED, SEED + 1, halo=False)  # warm-up
+        res = host_mirror.poly_commit_roundtrip(ctx, C, gs, hg, coeffs, r, x, SEED, SEED + 1, halo=True)
+        out["poly_commit_2_20"] = {"workload": "polynomial commitment opening, degree 2^20 - 1, CRS resident",
+                                   "prove_ms": res["prove_ms"], "verify_ms": res["verify_ms"],
+                                   "all_verified": bool(res["verify_ok"] and res["lazy_ok"] and res["halo_ok"])}
+    return out
+
+
 def cpu_baseline(n_sample):
     """C oracle (oracle/bp_oracle.c, a port of the bucket method) on all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -368,6 +418,8 @@ def main():
             out["range_proofs"] = range_proofs(ctx, local_rank, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_in_flight:
             out["msm_two_in_flight"] = msm_in_flight(bp, local_rank, dx, dy, dk, n, args.steps)
+        if world == 1 and not args.no_range:
+            out["other_configs"] = other_configs(ctx, px, py)
         assert res is not None
         print(json.dumps(out), flush=True)
     if use_dist:
