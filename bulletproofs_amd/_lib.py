@@ -111,6 +111,8 @@ SIGNATURES = {
     "bp_bases_precompute": (ci, [vp]),
     "bp_msm_resident_s_vector": (ci, [vp, vp, sz, vp, vp, sz, vp]),
     "bp_bases_register_compressed": (ci, [vp, ci, vp, sz, C.POINTER(vp)]),
+    "bp_scalars_to_bytes": (ci, [vp, ci, vp, sz, vp]),
+    "bp_scalars_from_bytes": (ci, [vp, ci, vp, sz, vp, vp]),
     "bp_points_compress": (ci, [vp, ci, vp, vp, vp, sz, vp]),
     "bp_points_decompress": (ci, [vp, ci, vp, sz, vp, vp, vp, vp]),
     "bp_ipa_begin_resident": (ci, [vp, vp, ci, sz, sz, vp, vp, sz, C.POINTER(vp)]),

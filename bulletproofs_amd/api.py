@@ -301,6 +301,22 @@ class Context:
         self._chk(lib.bp_scale_points(self.h, curve, _p(px), _p(py), _p(pi), _p(s), n, _p(ox), _p(oy), _p(oi)))
         return ox, oy, oi
 
+    def scalars_to_bytes(self, curve, v):
+        """(n, 32) bytes: canonical little-endian integers of scalar-field elements (bp_scalars_to_bytes)"""
+        v = _f(v)
+        out = np.zeros((v.shape[0], 32), dtype=np.uint8)
+        self._chk(lib.bp_scalars_to_bytes(self.h, curve, _p(v), v.shape[0], _p(out)))
+        return out
+
+    def scalars_from_bytes(self, curve, data):
+        """(n, 32) bytes -> Montgomery limbs, ok (0 where the integer is not below the group order)"""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 32)
+        n = data.shape[0]
+        out = np.zeros((n, 4), dtype=np.uint64)
+        ok = np.zeros(n, dtype=np.uint8)
+        self._chk(lib.bp_scalars_from_bytes(self.h, curve, _p(data), n, _p(out), _p(ok)))
+        return out, ok
+
     def points_compress(self, curve, points):
         """ark-serialize's compressed encoding of affine points: (n, 33) bytes (bp_points_compress)"""
         px, py, pi = _pts(points)

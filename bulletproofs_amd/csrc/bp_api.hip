@@ -1307,6 +1307,38 @@ int bp_scale_points(bp_ctx* ctx, int curve, const uint64_t* px, const uint64_t* 
   return BP_OK;
 }
 
+int bp_scalars_to_bytes(bp_ctx* ctx, int curve, const uint64_t* v, size_t n, uint8_t* out) {
+  if (!ctx || (n && (!v || !out))) return fail(ctx, BP_E_ARG, "bp_scalars_to_bytes: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) return BP_OK;
+  void *dv, *dout;
+  CHK(upload(ctx, S_IN0, v, n * 32, &dv));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dout));
+  hipError_t e = launch_scalars_to_bytes(curve, (const u32*)dv, n, (u32*)dout, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "scalars_to_bytes", e);
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_scalars_from_bytes(bp_ctx* ctx, int curve, const uint8_t* in, size_t n, uint64_t* out, uint8_t* out_ok) {
+  if (!ctx || (n && (!in || !out || !out_ok))) return fail(ctx, BP_E_ARG, "bp_scalars_from_bytes: null argument");
+  if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
+  Guard g(ctx);
+  if (n == 0) return BP_OK;
+  void *din, *dv, *dok;
+  CHK(upload(ctx, S_IN0, in, n * 32, &din));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dv));
+  CHK(reserve(ctx, S_OUT2, n, &dok));
+  hipError_t e = launch_scalars_from_bytes(curve, (const u32*)din, n, (u32*)dv, (uint8_t*)dok, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "scalars_from_bytes", e);
+  HIPCHK(ctx, hipMemcpyAsync(out, dv, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out_ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
 int bp_points_compress(bp_ctx* ctx, int curve, const uint64_t* px, const uint64_t* py, const uint8_t* pinf, size_t n,
                        uint8_t* out) {
   if (!ctx || (n && (!px || !py || !out))) return fail(ctx, BP_E_ARG, "bp_points_compress: null argument");

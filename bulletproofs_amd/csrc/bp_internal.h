@@ -38,6 +38,8 @@ size_t s_vector_table_elems(int k);
 // compressed point encoding of ark-serialize (33 bytes per point), bp_wire.hip
 hipError_t launch_points_compress(int curve, const u32* x, const u32* y, const uint8_t* inf, size_t n, uint8_t* out,
                                   hipStream_t st);
+hipError_t launch_scalars_to_bytes(int curve, const u32* v, size_t n, u32* out, hipStream_t st);
+hipError_t launch_scalars_from_bytes(int curve, const u32* in, size_t n, u32* v, uint8_t* ok, hipStream_t st);
 hipError_t launch_points_decompress(int curve, const uint8_t* in, size_t n, u32* x, u32* y, uint8_t* inf, uint8_t* ok,
                                     hipStream_t st);
 hipError_t launch_powers(int curve, FeArg x, size_t n, u32* table, u32* out, hipStream_t st);

@@ -196,6 +196,26 @@ __global__ __launch_bounds__(256) void k_points_decompress(const uint8_t* __rest
   ok[i] = good ? 1 : 0;
 }
 
+// Scalars: the canonical integer in 32 little-endian bytes (ark-serialize writes a field element
+// without flags in ceil(bits / 8) bytes: 32 for both scalar fields); a value >= the modulus is no scalar.
+template <class F>
+__global__ __launch_bounds__(256) void k_scalars_to_bytes(const u32* __restrict__ v, size_t n, u32* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe_store(out + i * 8, fe_from_mont<F>(fe_load(v + i * 8)));  // little-endian limbs are little-endian bytes
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_scalars_from_bytes(const u32* __restrict__ in, size_t n, u32* __restrict__ v,
+                                                            uint8_t* __restrict__ ok) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fe c = fe_load(in + i * 8);
+  const bool good = below_modulus<F>(c);
+  fe_store(v + i * 8, good ? fe_to_mont<F>(c) : fe_zero());
+  ok[i] = good ? 1 : 0;
+}
+
 }  // namespace
 
 #define DISPATCH_CURVE_W(curve, STMT) \
@@ -226,6 +246,21 @@ hipError_t launch_points_decompress(int curve, const uint8_t* in, size_t n, u32*
   const unsigned blocks = (unsigned)((n + 255) / 256);
   DISPATCH_CURVE_W(curve,
                    hipLaunchKernelGGL(k_points_decompress<C>, dim3(blocks), dim3(256), 0, st, in, n, x, y, inf, ok));
+  return hipGetLastError();
+}
+
+hipError_t launch_scalars_to_bytes(int curve, const u32* v, size_t n, u32* out, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  DISPATCH_CURVE_W(curve, hipLaunchKernelGGL(k_scalars_to_bytes<typename C::Fr>, dim3(blocks), dim3(256), 0, st, v, n, out));
+  return hipGetLastError();
+}
+
+hipError_t launch_scalars_from_bytes(int curve, const u32* in, size_t n, u32* v, uint8_t* ok, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  DISPATCH_CURVE_W(curve,
+                   hipLaunchKernelGGL(k_scalars_from_bytes<typename C::Fr>, dim3(blocks), dim3(256), 0, st, in, n, v, ok));
   return hipGetLastError();
 }
 

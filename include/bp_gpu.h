@@ -290,6 +290,13 @@ int bp_points_decompress(bp_ctx* ctx, int curve, const uint8_t* in, size_t n, ui
  * message of bp_last_error names the first one. */
 int bp_bases_register_compressed(bp_ctx* ctx, int curve, const uint8_t* bytes, size_t n,
                                  bp_bases** out);
+/* Scalars on the wire: the canonical integer in 32 little-endian bytes (CanonicalSerialize of a
+ * scalar-field element, e.g. the a, b, tao_x, mu, t_hat of a proof or a coefficient vector read from
+ * bytes).  bp_scalars_to_bytes writes n * 32 bytes; bp_scalars_from_bytes returns Montgomery limbs
+ * and out_ok[i] = 0 (value 0) where the integer is not below the group order. */
+int bp_scalars_to_bytes(bp_ctx* ctx, int curve, const uint64_t* v, size_t n, uint8_t* out);
+int bp_scalars_from_bytes(bp_ctx* ctx, int curve, const uint8_t* in, size_t n, uint64_t* out,
+                          uint8_t* out_ok);
 /* Jacobian (n*12 u64) -> affine: G::normalize_batch at src/ipa/mod.rs:187,226,
  * src/range/aggregate.rs:223. */
 int bp_normalize_batch(bp_ctx* ctx, int curve, const uint64_t* xyz, size_t n, uint64_t* out_x,

@@ -133,3 +133,22 @@ def test_gpu_base_set_from_compressed_points(ctx, c):
     with pytest.raises(BpError) as err:
         ctx.register_bases_compressed(c.id, data)
     assert "point 11" in str(err.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_gpu_scalars_on_the_wire(ctx, c):
+    """bp_scalars_to_bytes / bp_scalars_from_bytes: canonical little-endian integers, values that are not
+    below the group order refused"""
+    rng = o.SplitMix64(0x5CA1A + c.id)
+    vals = [0, 1, c.n - 1, c.n // 2] + rng.scalars(300, c.n)
+    got = ctx.scalars_to_bytes(c.id, o.pack_field(vals, c.n))
+    expect = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(len(vals), 32)
+    assert np.array_equal(got, expect)
+    back, ok = ctx.scalars_from_bytes(c.id, got)
+    assert ok.all() and o.unpack_field(back, c.n) == vals
+    bad = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in (c.n, c.n + 5, (1 << 256) - 1, c.n - 1)),
+                        dtype=np.uint8).reshape(4, 32)
+    back, ok = ctx.scalars_from_bytes(c.id, bad)
+    assert ok.tolist() == [0, 0, 0, 1]
+    assert o.unpack_field(back, c.n) == [0, 0, 0, c.n - 1]
