@@ -152,3 +152,33 @@ def test_gpu_scalars_on_the_wire(ctx, c):
     back, ok = ctx.scalars_from_bytes(c.id, bad)
     assert ok.tolist() == [0, 0, 0, 1]
     assert o.unpack_field(back, c.n) == [0, 0, 0, c.n - 1]
+
+
+@pytest.mark.gpu
+def test_gpu_range_proof_as_bytes(ctx):
+    """a range proof written as the byte string of its prover messages and read back: every message equal,
+    length as the message list gives it, and a damaged element or a wrong length refused"""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import host_mirror, wire
+
+    m, n_bits = 4, 8
+    gs, hs, ugh, values, gamma = host_mirror.range_bench_inputs(ctx, m, n_bits, 0xB17E5)
+    proof = host_mirror.range_aggregate_roundtrip(ctx, bp.SECP256K1, gs, hs, ugh, values, gamma, n_bits, 11, 12)
+    assert proof["ok"]
+    k = (m * n_bits).bit_length() - 1
+    data = wire.range_proof_to_bytes(ctx, bp.SECP256K1, proof)
+    assert len(data) == wire.range_proof_len(k) == (4 + 2 * k) * 33 + 5 * 32
+    back, ok = wire.range_proof_from_bytes(ctx, bp.SECP256K1, data, k)
+    assert ok
+    for key in ("A", "S", "TT1", "TT2", "tao_x", "mu", "t_hat", "L", "R", "a", "b"):
+        assert np.array_equal(np.asarray(back[key]), np.asarray(proof[key])), key
+    # the first point's x replaced by the field modulus: no point
+    p = (1 << 256) - (1 << 32) - 977
+    bad = p.to_bytes(32, "little") + data[32:]
+    assert wire.range_proof_from_bytes(ctx, bp.SECP256K1, bad, k) == (None, False)
+    # a scalar that is not below the group order
+    off = 4 * 33
+    bad = data[:off] + b"\xff" * 32 + data[off + 32:]
+    assert wire.range_proof_from_bytes(ctx, bp.SECP256K1, bad, k) == (None, False)
+    assert wire.range_proof_from_bytes(ctx, bp.SECP256K1, data, k + 1) == (None, False)
+    assert wire.range_proof_from_bytes(ctx, bp.SECP256K1, data[:-1], k) == (None, False)
