@@ -1217,6 +1217,62 @@ int bp_range_agg_verify_scalars(bp_ctx* ctx, int curve, const uint64_t* challeng
   return BP_OK;
 }
 
+int bp_range_agg_verify_msm(bp_ctx* ctx, const bp_bases* bases, const uint64_t* challenges, const uint64_t* challenge_invs,
+                            size_t k, const uint64_t a[4], const uint64_t b[4], const uint64_t y_inv[4], const uint64_t z[4],
+                            size_t m, unsigned n_bits, const uint64_t u_scalar[4], const uint64_t* extra_x,
+                            const uint64_t* extra_y, const uint8_t* extra_inf, const uint64_t* extra_scalars, size_t n_extra,
+                            uint64_t out_xyz[12]) {
+  if (!ctx || !bases || !a || !b || !y_inv || !z || !u_scalar || !out_xyz || (k && (!challenges || !challenge_invs)) ||
+      (n_extra && (!extra_x || !extra_y || !extra_scalars)))
+    return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: bases belong to another context");
+  if (k > 28 || m == 0 || n_bits == 0 || n_bits > 64 || m * (size_t)n_bits != ((size_t)1 << k))
+    return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: m * n_bits must be 2^k");
+  const size_t n = (size_t)1 << k;
+  if (bases->n < 2 * n + 1) return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: base set shorter than 2 * m * n_bits + 1");
+  const int curve = bases->curve;
+  Guard g(ctx);
+  std::vector<uint64_t> tab(4 * (m + n_bits));
+  if (curve == BP_SECP256K1)
+    range_tables<Secp256k1Fr>(z, m, n_bits, tab.data(), tab.data() + 4 * m);
+  else
+    range_tables<VestaFr>(z, m, n_bits, tab.data(), tab.data() + 4 * m);
+  void *dch = nullptr, *dchi = nullptr, *dtab, *dt, *dss, *dssi, *dyi, *dsc;
+  if (k) {
+    CHK(upload(ctx, S_IN0, challenges, k * 32, &dch));
+    CHK(upload(ctx, S_IN1, challenge_invs, k * 32, &dchi));
+  }
+  CHK(upload(ctx, S_IN2, tab.data(), tab.size() * 8, &dtab));
+  size_t te = s_vector_table_elems((int)k), pe = powers_table_elems(n);
+  CHK(reserve(ctx, S_TABLE, (te > pe ? te : pe) * 32, &dt));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dss));
+  CHK(reserve(ctx, S_OUT1, n * 32, &dssi));
+  CHK(reserve(ctx, S_OUT2, n * 32, &dyi));
+  // the scalars of gs | hs | u in one vector, where the MSM reads them
+  CHK(reserve(ctx, S_IN5, (2 * n + 1) * 32, &dsc));
+  u32* dg = (u32*)dsc;
+  u32* dh = dg + n * 8;
+  hipError_t e = launch_s_vector(curve, (const u32*)dch, (const u32*)dchi, (int)k, (u32*)dt, (u32*)dss, ctx->stream);
+  if (e == hipSuccess) e = launch_s_vector(curve, (const u32*)dchi, (const u32*)dch, (int)k, (u32*)dt, (u32*)dssi, ctx->stream);
+  if (e == hipSuccess) e = launch_powers(curve, to_arg(y_inv), n, (u32*)dt, (u32*)dyi, ctx->stream);
+  if (e == hipSuccess)
+    e = launch_range_verify_scalars(curve, (const u32*)dss, (const u32*)dssi, (const u32*)dyi, (const u32*)dtab,
+                                    (const u32*)dtab + 8 * m, n_bits, n, to_arg(a), to_arg(b), to_arg(z), dg, dh, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "range_verify_scalars", e);
+  HIPCHK(ctx, hipMemcpyAsync(dg + 2 * n * 8, u_scalar, 32, hipMemcpyHostToDevice, ctx->stream));
+  void *dx = nullptr, *dy = nullptr, *di = nullptr, *des = nullptr;
+  if (n_extra) {
+    // the slots of the challenges and tables are free again in stream order
+    CHK(upload(ctx, S_IN3, extra_x, n_extra * 32, &dx));
+    CHK(upload(ctx, S_IN4, extra_y, n_extra * 32, &dy));
+    if (extra_inf) CHK(upload(ctx, S_IN6, extra_inf, n_extra, &di));
+    CHK(upload(ctx, S_AOS, extra_scalars, n_extra * 32, &des));
+  }
+  MsmPart p0{bases->x, bases->y, bases->inf, (const u32*)dsc, 2 * n + 1};
+  MsmPart p1{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)des, n_extra};
+  return msm_full(ctx, curve, p0, p1, out_xyz);
+}
+
 int bp_batch_inverse(bp_ctx* ctx, int curve, int field, uint64_t* v, size_t n) {
   if (!ctx || (n && !v) || (field != 0 && field != 1)) return fail(ctx, BP_E_ARG, "bp_batch_inverse: bad argument");
   if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");

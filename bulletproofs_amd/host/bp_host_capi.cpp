@@ -265,19 +265,26 @@ int range_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const u
         continue;
       }
       auto c = std::chrono::steady_clock::now();
-      auto msm = single ? R1::verify_aux(ctx, crs, vcom[0], n_bits, check_proof, t2, vrng)
-                        : R::verify_aux(ctx, crs, vcom, n_bits, check_proof, t2, vrng);
-      value = msm.execute();
+      // the verifier with the scalars of gs and hs kept on the device (bp_range_agg_verify_msm)
+      value = single ? R1::verify_value(ctx, crs, vcom[0], n_bits, check_proof, t2, vrng)
+                     : R::verify_value(ctx, crs, vcom, n_bits, check_proof, t2, vrng);
       bool good = is_zero(value);  // src/range/aggregate.rs:294-299, src/range/mod.rs:261-267
       auto d = std::chrono::steady_clock::now();
       if (!good) *ok = 0;
       if (r == 0) {
-        // the verifier in the reference's order of operations reaches the same group element
-        // (the identity for a valid proof, some other point for a corrupted one)
+        // the accumulator form (scalars through the host, as batch verification uses it) and the verifier
+        // in the reference's order of operations reach the same group element (the identity for a
+        // valid proof, some other point for a corrupted one)
+        SeededTranscript<Fr> t4(seed_chal);
+        SeededRandom<Fr> vrng4(seed_rand ^ 0x5EEDull);
+        auto msm = single ? R1::verify_aux(ctx, crs, vcom[0], n_bits, check_proof, t4, vrng4)
+                          : R::verify_aux(ctx, crs, vcom, n_bits, check_proof, t4, vrng4);
+        if (memcmp(msm.execute().xyz, value.xyz, 96) != 0)
+          throw std::runtime_error("verifier with device-resident scalars and accumulator verifier disagree");
         SeededTranscript<Fr> t3(seed_chal);
         SeededRandom<Fr> vrng3(seed_rand ^ 0x5EEDull);
         Projective stepwise = R::verify_aux_stepwise(ctx, crs, vcom, n_bits, check_proof, t3, vrng3).execute();
-        if (memcmp(stepwise.xyz, msm.execute().xyz, 96) != 0)
+        if (memcmp(stepwise.xyz, value.xyz, 96) != 0)
           throw std::runtime_error("single-MSM verifier and stepwise verifier disagree");
       }
       tp += std::chrono::duration<double, std::milli>(b - a).count();
@@ -349,7 +356,7 @@ int range_throughput(int device, const uint64_t* gx, const uint64_t* gy, const u
         proofs[0] = R::prove(ctx, crs, vals, gam, n_bits, t, rng);
         SeededTranscript<Fr> t2(seed_chal + w);
         SeededRandom<Fr> vrng(seed_rand ^ 0x5EEDull);
-        if (!is_zero(R::verify_aux(ctx, crs, vcom, n_bits, proofs[0], t2, vrng).execute())) failures++;
+        if (!R::verify(ctx, crs, vcom, n_bits, proofs[0], t2, vrng)) failures++;
       }
       reached[0] = true; rendezvous(0);
       p0[w] = clock::now();
@@ -364,7 +371,7 @@ int range_throughput(int device, const uint64_t* gx, const uint64_t* gy, const u
       for (int r = 0; r < reps; r++) {
         SeededTranscript<Fr> t(seed_chal + w + 1000 * r);
         SeededRandom<Fr> vrng(seed_rand ^ 0x5EEDull);
-        if (!is_zero(R::verify_aux(ctx, crs, vcom, n_bits, proofs[r], t, vrng).execute())) failures++;
+        if (!R::verify(ctx, crs, vcom, n_bits, proofs[r], t, vrng)) failures++;
       }
       v1[w] = clock::now();
       reached[2] = true; rendezvous(2);

@@ -170,10 +170,20 @@ struct RangeAggregate {
   // instead: gs_i and hs_i collect a*s_i + z and y^-i (b*s_i^-1 - z^(2+j) 2^i) - z (built on the
   // device, bp_range_agg_verify_scalars), and A, S, T1, T2, V_j, L_j, R_j, g, h, u carry the rest.
   // execute() returns the point verify_aux_stepwise's accumulator evaluates to.
-  static M verify_aux(bp_ctx* ctx, const Crs& crs, const std::vector<Projective>& v_commit, unsigned n_bits,
-                      const RangeProof& pr, Transcript& t, RandomSource& rng) {
+  // The host's part of verify_aux: the challenges, and every term of the deferred MSM that is not a
+  // scalar of gs or hs.  No device call.
+  struct VerifyPlan {
+    size_t k = 0, m = 0, n = 0;
+    std::vector<Scalar> xs, xinv;
+    Scalar y_inv, z, u_scalar;
+    std::vector<std::pair<Affine, Scalar>> terms;  // in the order the reference meets them
+  };
+  static VerifyPlan verify_plan(const Crs& crs, const std::vector<Projective>& v_commit, unsigned n_bits,
+                                const RangeProof& pr, Transcript& t, RandomSource& rng) {
+    VerifyPlan vp;
     const size_t m = v_commit.size(), n = (size_t)n_bits * m;
     if (n != crs.n) throw std::invalid_argument("CRS registered for another size");
+    vp.m = m; vp.n = n;
     const Scalar one = S::one();
     Projective as[2] = {pr.a, pr.s};
     t.prover_points(as, 2);
@@ -186,7 +196,10 @@ struct RangeAggregate {
     Scalar xe = t.verifier_scalar();
     // the inner-product argument's challenges (src/ipa/mod.rs:116-132)
     const size_t k = checked_rounds(pr.ipa.L.size(), pr.ipa.R.size(), n);
-    std::vector<Scalar> xs(k), xinv(k);
+    vp.k = k;
+    std::vector<Scalar>& xs = vp.xs;
+    std::vector<Scalar>& xinv = vp.xinv;
+    xs.resize(k); xinv.resize(k);
     for (size_t j = 0; j < k; j++) {
       Projective lr[2] = {pr.ipa.L[j], pr.ipa.R[j]};
       t.prover_points(lr, 2);
@@ -203,6 +216,7 @@ struct RangeAggregate {
       y_inv = out[k];
       ym1_inv = out[k + 1];
     }
+    vp.y_inv = y_inv; vp.z = z;
     Scalar zz = S::mul(z, z);
     // delta(y,z) = (z - z^2) <1, y^N> - sum_j z^(3+j) <1, 2^n>   (:209-215); <1, y^N> = (y^N - 1)/(y - 1)
     Scalar sum_y;
@@ -216,38 +230,75 @@ struct RangeAggregate {
     Scalar zsum = S::zero(), zp = S::mul(zz, z);
     for (size_t j = 0; j < m; j++) { zsum = S::add(zsum, zp); zp = S::mul(zp, z); }
     Scalar delta = sub(S::mul(sub(z, zz), sum_y), S::mul(zsum, d));
+    // u: a*b*x' from the inner-product verifier (src/ipa/mod.rs:125, scale_elem :270) minus x'*t_hat from P
+    vp.u_scalar = S::mul(xe, sub(S::mul(pr.ipa.a, pr.ipa.b), pr.t_hat));
+    auto term = [&](const Affine& p, const Scalar& s) { vp.terms.emplace_back(p, s); };
+    Scalar minus_one = S::neg(one);
+    // -P = -A - x S + mu h (+ the gs, hs and u parts)   (:259-264)
+    term(P::to_affine(pr.a), minus_one);
+    term(P::to_affine(pr.s), S::neg(x));
+    term(crs.h, pr.mu);
+    for (size_t j = 0; j < k; j++) {                                             // src/ipa/mod.rs:170-190
+      term(P::to_affine(pr.ipa.L[j]), S::neg(S::mul(xs[j], xs[j])));
+      term(P::to_affine(pr.ipa.R[j]), S::neg(S::mul(xinv[j], xinv[j])));
+    }
+    // rho * ((t_hat - delta) g + tao_x h - sum_j z^(2+j) V_j - x T1 - x^2 T2)   (:217-227, :278-279)
+    Scalar rho = rng.scalar();
+    term(crs.g, S::mul(rho, sub(pr.t_hat, delta)));
+    term(crs.h, S::mul(rho, pr.tao_x));
+    zp = zz;
+    for (size_t j = 0; j < m; j++) {
+      term(P::to_affine(v_commit[j]), S::neg(S::mul(rho, zp)));
+      zp = S::mul(zp, z);
+    }
+    term(P::to_affine(pr.tt1), S::neg(S::mul(rho, x)));
+    term(P::to_affine(pr.tt2), S::neg(S::mul(rho, S::mul(x, x))));
+    return vp;
+  }
+
+  static M verify_aux(bp_ctx* ctx, const Crs& crs, const std::vector<Projective>& v_commit, unsigned n_bits,
+                      const RangeProof& pr, Transcript& t, RandomSource& rng) {
+    const VerifyPlan vp = verify_plan(crs, v_commit, n_bits, pr, t, rng);
+    const size_t n = vp.n, k = vp.k;
     // scalars of gs and hs
     std::vector<Scalar> gsc(n), hsc(n);
-    Scalar dummy = one;
-    check(ctx, bp_range_agg_verify_scalars(ctx, CURVE, k ? xs[0].l : dummy.l, k ? xinv[0].l : dummy.l, k, pr.ipa.a.l,
-                                           pr.ipa.b.l, y_inv.l, z.l, m, n_bits, gsc[0].l, hsc[0].l),
+    Scalar dummy = S::one();
+    check(ctx, bp_range_agg_verify_scalars(ctx, CURVE, k ? vp.xs[0].l : dummy.l, k ? vp.xinv[0].l : dummy.l, k, pr.ipa.a.l,
+                                           pr.ipa.b.l, vp.y_inv.l, vp.z.l, vp.m, n_bits, gsc[0].l, hsc[0].l),
           "bp_range_agg_verify_scalars");
     M msm(ctx, crs.gh, 2 * n + 1);
     msm.upsert_resident_range(0, gsc);
     msm.upsert_resident_range(n, hsc);
-    // u: a*b*x' from the inner-product verifier (src/ipa/mod.rs:125, scale_elem :270) minus x'*t_hat from P
-    msm.upsert_resident(2 * n, S::mul(xe, sub(S::mul(pr.ipa.a, pr.ipa.b), pr.t_hat)));
-    Scalar minus_one = S::neg(one);
-    // -P = -A - x S + mu h (+ the gs, hs and u parts above)   (:259-264)
-    msm.upsert(P::to_affine(pr.a), minus_one);
-    msm.upsert(P::to_affine(pr.s), S::neg(x));
-    msm.upsert(crs.h, pr.mu);
-    for (size_t j = 0; j < k; j++) {                                             // src/ipa/mod.rs:170-190
-      msm.upsert(P::to_affine(pr.ipa.L[j]), S::neg(S::mul(xs[j], xs[j])));
-      msm.upsert(P::to_affine(pr.ipa.R[j]), S::neg(S::mul(xinv[j], xinv[j])));
-    }
-    // rho * ((t_hat - delta) g + tao_x h - sum_j z^(2+j) V_j - x T1 - x^2 T2)   (:217-227, :278-279)
-    Scalar rho = rng.scalar();
-    msm.upsert(crs.g, S::mul(rho, sub(pr.t_hat, delta)));
-    msm.upsert(crs.h, S::mul(rho, pr.tao_x));
-    zp = zz;
-    for (size_t j = 0; j < m; j++) {
-      msm.upsert(P::to_affine(v_commit[j]), S::neg(S::mul(rho, zp)));
-      zp = S::mul(zp, z);
-    }
-    msm.upsert(P::to_affine(pr.tt1), S::neg(S::mul(rho, x)));
-    msm.upsert(P::to_affine(pr.tt2), S::neg(S::mul(rho, S::mul(x, x))));
+    msm.upsert_resident(2 * n, vp.u_scalar);
+    for (const auto& pt : vp.terms) msm.upsert(pt.first, pt.second);
     return msm;
+  }
+
+  // The same check without the accumulator: the scalars of gs and hs never leave the device
+  // (bp_range_agg_verify_msm).  Returns the group element the deferred MSM evaluates to (the value of
+  // verify_aux(...).execute()): the identity iff the proof is valid.
+  static Projective verify_value(bp_ctx* ctx, const Crs& crs, const std::vector<Projective>& v_commit, unsigned n_bits,
+                                 const RangeProof& pr, Transcript& t, RandomSource& rng) {
+    const VerifyPlan vp = verify_plan(crs, v_commit, n_bits, pr, t, rng);
+    const size_t ne = vp.terms.size(), k = vp.k;
+    std::vector<uint64_t> x(4 * ne + 4), y(4 * ne + 4), sc(4 * ne + 4);
+    std::vector<uint8_t> inf(ne + 1);
+    for (size_t i = 0; i < ne; i++) {
+      memcpy(&x[4 * i], vp.terms[i].first.x, 32); memcpy(&y[4 * i], vp.terms[i].first.y, 32);
+      inf[i] = vp.terms[i].first.inf;
+      memcpy(&sc[4 * i], vp.terms[i].second.l, 32);
+    }
+    Scalar dummy = S::one();
+    Projective out;
+    check(ctx, bp_range_agg_verify_msm(ctx, crs.gh, k ? vp.xs[0].l : dummy.l, k ? vp.xinv[0].l : dummy.l, k, pr.ipa.a.l,
+                                       pr.ipa.b.l, vp.y_inv.l, vp.z.l, vp.m, n_bits, vp.u_scalar.l, x.data(), y.data(),
+                                       inf.data(), sc.data(), ne, out.xyz),
+          "bp_range_agg_verify_msm");
+    return out;
+  }
+  static bool verify(bp_ctx* ctx, const Crs& crs, const std::vector<Projective>& v_commit, unsigned n_bits,
+                     const RangeProof& pr, Transcript& t, RandomSource& rng) {
+    return is_zero(verify_value(ctx, crs, v_commit, n_bits, pr, t, rng));
   }
 
   // The same verifier in the reference's order of operations (every intermediate group element
@@ -362,9 +413,13 @@ struct Range {
     return A::verify_aux(ctx, crs, std::vector<Projective>{v_commit}, n_bits, pr, t, rng);
   }
   // range::verify, src/range/mod.rs:252-268
+  static Projective verify_value(bp_ctx* ctx, const Crs& crs, const Projective& v_commit, unsigned n_bits,
+                                 const RangeProof& pr, Transcript& t, RandomSource& rng) {
+    return A::verify_value(ctx, crs, std::vector<Projective>{v_commit}, n_bits, pr, t, rng);
+  }
   static bool verify(bp_ctx* ctx, const Crs& crs, const Projective& v_commit, unsigned n_bits, const RangeProof& pr,
                      Transcript& t, RandomSource& rng) {
-    return is_zero(verify_aux(ctx, crs, v_commit, n_bits, pr, t, rng).execute());
+    return is_zero(verify_value(ctx, crs, v_commit, n_bits, pr, t, rng));
   }
 };
 

@@ -251,6 +251,18 @@ int bp_range_agg_eval(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uin
 int bp_range_agg_verify_scalars(bp_ctx* ctx, int curve, const uint64_t* challenges, const uint64_t* challenge_invs,
                                 size_t k, const uint64_t a[4], const uint64_t b[4], const uint64_t y_inv[4],
                                 const uint64_t z[4], size_t m, unsigned n_bits, uint64_t* out_g, uint64_t* out_h);
+/* The whole deferred check of the aggregated range verifier in one call: the scalars of
+ * bp_range_agg_verify_scalars are built on the device and stay there as the scalars of
+ * bases[0, n) (gs) and bases[n, 2n) (hs), u = bases[2n] takes u_scalar, the n_extra other terms
+ * (A, S, T1, T2, V_j, L_j, R_j, g, h: src/range/aggregate.rs:217-227,259-264,278-279) come from the
+ * host, and out_xyz is the MSM over all of them: the proof is valid iff it is the identity.  Saves
+ * the round trip of 2n scalars to the host and back that the two-step form pays. */
+int bp_range_agg_verify_msm(bp_ctx* ctx, const bp_bases* bases, const uint64_t* challenges,
+                            const uint64_t* challenge_invs, size_t k, const uint64_t a[4],
+                            const uint64_t b[4], const uint64_t y_inv[4], const uint64_t z[4], size_t m,
+                            unsigned n_bits, const uint64_t u_scalar[4], const uint64_t* extra_x,
+                            const uint64_t* extra_y, const uint8_t* extra_inf,
+                            const uint64_t* extra_scalars, size_t n_extra, uint64_t out_xyz[12]);
 /* out[i] = x^i, i < n: powers_of_x src/poly_commit/mod.rs:16-22, y_vec
  * src/range/aggregate.rs:88-91, hs' scalars src/range/utils.rs:22-29. */
 int bp_powers(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* out);
