@@ -198,6 +198,14 @@ for _ in range(3):
     ts.append(time.perf_counter() - t0)
 print(json.dumps({"kernel": "ipa_verify", "n": n, "msm_points": 2 * n + 34, "total_ms": min(ts) * 1e3,
                   "verifies_per_s": 1 / min(ts)}), flush=True)
+# the same check with the scalars built where the MSM reads them (bp_ipa_verify_msm)
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    bases.ipa_verify_msm(0, n, 2 * n, ch, chi, pa, pb, ctx.hadamard(C, pa, pb), extra, extra_s)
+    ts.append(time.perf_counter() - t0)
+print(json.dumps({"kernel": "ipa_verify_fused", "n": n, "msm_points": 2 * n + 34, "total_ms": min(ts) * 1e3,
+                  "verifies_per_s": 1 / min(ts)}), flush=True)
 bases.free()
 
 # ---- points from bytes: a CRS of 2^20 compressed points decoded into a base set (host bytes in) ----

@@ -393,6 +393,18 @@ class Bases:
     def __len__(self):
         return lib.bp_bases_len(self.h)
 
+    def ipa_verify_msm(self, g_offset, h_offset, u_index, challenges, challenge_inverses, a, b, u_scalar, extra, extra_scalars):
+        """the inner-product verifier's deferred MSM with its scalars built on the device
+        (bp_ipa_verify_msm; src/ipa/mod.rs:102-193): returns the group element, the identity iff valid"""
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(-1, 4)
+        chi = np.ascontiguousarray(challenge_inverses, dtype=np.uint64).reshape(-1, 4)
+        ex, ey, ei = _pts(extra)
+        es, a, b, us = _f(extra_scalars), _f(a), _f(b), _f(u_scalar)  # named: the arrays must outlive the call
+        out = np.zeros(12, dtype=np.uint64)
+        self.ctx._chk(lib.bp_ipa_verify_msm(self.ctx.h, self.h, g_offset, h_offset, u_index, _p(ch), _p(chi), ch.shape[0],
+                                            _p(a), _p(b), _p(us), _p(ex), _p(ey), _p(ei), _p(es), ex.shape[0], _p(out)))
+        return out
+
     def precompute(self):
         """window tables for this base set (bp_bases_precompute)"""
         self.ctx._chk(lib.bp_bases_precompute(self.h))

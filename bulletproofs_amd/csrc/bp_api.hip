@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -1269,6 +1270,59 @@ int bp_range_agg_verify_msm(bp_ctx* ctx, const bp_bases* bases, const uint64_t* 
     CHK(upload(ctx, S_AOS, extra_scalars, n_extra * 32, &des));
   }
   MsmPart p0{bases->x, bases->y, bases->inf, (const u32*)dsc, 2 * n + 1};
+  MsmPart p1{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)des, n_extra};
+  return msm_full(ctx, curve, p0, p1, out_xyz);
+}
+
+int bp_ipa_verify_msm(bp_ctx* ctx, const bp_bases* bases, size_t g_offset, size_t h_offset, size_t u_index,
+                      const uint64_t* challenges, const uint64_t* challenge_invs, size_t k, const uint64_t a[4],
+                      const uint64_t b[4], const uint64_t u_scalar[4], const uint64_t* extra_x, const uint64_t* extra_y,
+                      const uint8_t* extra_inf, const uint64_t* extra_scalars, size_t n_extra, uint64_t out_xyz[12]) {
+  if (!ctx || !bases || !a || !b || !u_scalar || !out_xyz || (k && (!challenges || !challenge_invs)) ||
+      (n_extra && (!extra_x || !extra_y || !extra_scalars)))
+    return fail(ctx, BP_E_ARG, "bp_ipa_verify_msm: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_ipa_verify_msm: bases belong to another context");
+  if (k > 28) return fail(ctx, BP_E_ARG, "bp_ipa_verify_msm: too many rounds");
+  const size_t n = (size_t)1 << k, nb = bases->n;
+  if (g_offset > nb || n > nb - g_offset || h_offset > nb || n > nb - h_offset || u_index >= nb)
+    return fail(ctx, BP_E_ARG, "bp_ipa_verify_msm: range outside bases");
+  const bool overlap = (g_offset < h_offset + n && h_offset < g_offset + n) || (u_index >= g_offset && u_index < g_offset + n) ||
+                       (u_index >= h_offset && u_index < h_offset + n);
+  if (overlap) return fail(ctx, BP_E_ARG, "bp_ipa_verify_msm: gs, hs and u must not overlap");
+  const int curve = bases->curve;
+  Guard g(ctx);
+  // one scalar per point of bases[lo, hi): a s_i on gs, b s_i^-1 on hs, u_scalar on u, zero elsewhere
+  const size_t lo = std::min(std::min(g_offset, h_offset), u_index);
+  const size_t hi = std::max(std::max(g_offset + n, h_offset + n), u_index + 1);
+  void *dch = nullptr, *dchi = nullptr, *dt, *dss, *dsc;
+  if (k) {
+    CHK(upload(ctx, S_IN0, challenges, k * 32, &dch));
+    CHK(upload(ctx, S_IN1, challenge_invs, k * 32, &dchi));
+  }
+  CHK(reserve(ctx, S_TABLE, s_vector_table_elems((int)k) * 32, &dt));
+  CHK(reserve(ctx, S_OUT0, n * 32, &dss));
+  CHK(reserve(ctx, S_IN5, (hi - lo) * 32, &dsc));
+  u32* dense = (u32*)dsc;
+  if (hi - lo != 2 * n + 1) HIPCHK(ctx, hipMemsetAsync(dense, 0, (hi - lo) * 32, ctx->stream));
+  // no rounds: the s-vector of no challenges is (1)
+  hipError_t e = k ? launch_s_vector(curve, (const u32*)dch, (const u32*)dchi, (int)k, (u32*)dt, (u32*)dss, ctx->stream)
+                   : launch_fill_one(curve, (u32*)dss, 1, ctx->stream);
+  if (e == hipSuccess)  // src/ipa/mod.rs:134-148,160
+    e = launch_vec_op(curve, BP_VEC_SCALE, (const u32*)dss, nullptr, to_arg(a), n, dense + (g_offset - lo) * 8, ctx->stream);
+  if (e == hipSuccess && k)
+    e = launch_s_vector(curve, (const u32*)dchi, (const u32*)dch, (int)k, (u32*)dt, (u32*)dss, ctx->stream);
+  if (e == hipSuccess)  // :150-154,166
+    e = launch_vec_op(curve, BP_VEC_SCALE, (const u32*)dss, nullptr, to_arg(b), n, dense + (h_offset - lo) * 8, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_verify scalars", e);
+  HIPCHK(ctx, hipMemcpyAsync(dense + (u_index - lo) * 8, u_scalar, 32, hipMemcpyHostToDevice, ctx->stream));
+  void *dx = nullptr, *dy = nullptr, *di = nullptr, *des = nullptr;
+  if (n_extra) {
+    CHK(upload(ctx, S_IN3, extra_x, n_extra * 32, &dx));
+    CHK(upload(ctx, S_IN4, extra_y, n_extra * 32, &dy));
+    if (extra_inf) CHK(upload(ctx, S_IN6, extra_inf, n_extra, &di));
+    CHK(upload(ctx, S_AOS, extra_scalars, n_extra * 32, &des));
+  }
+  MsmPart p0{bases->x + lo * 8, bases->y + lo * 8, bases->inf + lo, (const u32*)dsc, hi - lo};
   MsmPart p1{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)des, n_extra};
   return msm_full(ctx, curve, p0, p1, out_xyz);
 }

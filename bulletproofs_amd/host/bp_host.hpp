@@ -495,6 +495,39 @@ struct Ipa {
     return msm;
   }
 
+  // The same check without the accumulator (bp_ipa_verify_msm): both s-vectors are built, scaled by a and
+  // b and used as the scalars of gs and hs on the device; returns the group element the deferred MSM
+  // evaluates to (the value of verify_aux_resident(...).execute()), the identity iff the proof is valid.
+  static Projective verify_value_resident(bp_ctx* ctx, const bp_bases* bases, size_t g_off, size_t h_off, size_t u_index,
+                                          const Projective& p, size_t n, const IpaProof& proof, Transcript& t) {
+    const size_t k = checked_rounds(proof.L.size(), proof.R.size(), n);
+    std::vector<Scalar> xs(k), xinv(k);
+    for (size_t j = 0; j < k; j++) {
+      Projective lr[2] = {proof.L[j], proof.R[j]};
+      t.prover_points(lr, 2);
+      xs[j] = t.verifier_scalar();
+    }
+    S::batch_inv(xs, xinv);                                                     // :128-132
+    const size_t ne = 2 * k + 1;
+    std::vector<uint64_t> x(4 * ne), y(4 * ne), sc(4 * ne);
+    std::vector<uint8_t> inf(ne);
+    Scalar minus_one = S::neg(S::one());                                        // :170-190
+    auto put = [&](size_t i, const Affine& q, const Scalar& s) {
+      memcpy(&x[4 * i], q.x, 32); memcpy(&y[4 * i], q.y, 32); inf[i] = q.inf; memcpy(&sc[4 * i], s.l, 32);
+    };
+    put(0, P::to_affine(p), minus_one);
+    for (size_t j = 0; j < k; j++) {
+      put(1 + 2 * j, P::to_affine(proof.L[j]), S::mul(minus_one, S::mul(xs[j], xs[j])));
+      put(2 + 2 * j, P::to_affine(proof.R[j]), S::mul(minus_one, S::mul(xinv[j], xinv[j])));
+    }
+    Scalar ab = S::mul(proof.a, proof.b), dummy = S::one();                     // :125
+    Projective out;
+    check(ctx, bp_ipa_verify_msm(ctx, bases, g_off, h_off, u_index, k ? xs[0].l : dummy.l, k ? xinv[0].l : dummy.l, k,
+                                 proof.a.l, proof.b.l, ab.l, x.data(), y.data(), inf.data(), sc.data(), ne, out.xyz),
+          "bp_ipa_verify_msm");
+    return out;
+  }
+
   // ipa::verify_aux, src/ipa/mod.rs:102-193; challenges are re-derived from the transcript
   static Msm<Fq, Fr, CURVE> verify_aux(bp_ctx* ctx, const Crs& crs, const Projective& p, size_t n, const IpaProof& proof,
                                        Transcript& t) {

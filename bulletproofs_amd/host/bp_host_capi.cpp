@@ -131,6 +131,10 @@ int ipa_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uin
       SeededTranscript<Fr> tw(seed + 1000 * pi);
       if (memcmp(I::verify_aux(ctx, crs, p, n, proof, tw).execute().xyz, value.xyz, 96) != 0)
         throw std::runtime_error("indexed and keyed accumulators disagree");
+      // and so does the verifier whose scalars never leave the device (bp_ipa_verify_msm)
+      SeededTranscript<Fr> tx(seed + 1000 * pi);
+      if (memcmp(I::verify_value_resident(ctx, gh, 0, n, 2 * n, p, n, proof, tx).xyz, value.xyz, 96) != 0)
+        throw std::runtime_error("verifier with device-resident scalars and accumulator verifier disagree");
     }
     msms.push_back(std::move(m));
   }

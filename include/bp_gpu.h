@@ -263,6 +263,17 @@ int bp_range_agg_verify_msm(bp_ctx* ctx, const bp_bases* bases, const uint64_t* 
                             unsigned n_bits, const uint64_t u_scalar[4], const uint64_t* extra_x,
                             const uint64_t* extra_y, const uint8_t* extra_inf,
                             const uint64_t* extra_scalars, size_t n_extra, uint64_t out_xyz[12]);
+/* The deferred check of the inner-product verifier (ipa::verify_aux, src/ipa/mod.rs:102-193) in one
+ * call over a registered CRS: gs = bases[g_offset, +2^k) take a * s_i, hs = bases[h_offset, +2^k) take
+ * b * s_i^-1 (the s-vector of the challenges and of their inverses, :134-166, built and scaled on the
+ * device), u = bases[u_index] takes u_scalar (a * b, :125), the n_extra other terms (P, L_j, R_j with
+ * -1, -x_j^2, -x_j^-2, :170-190) come from the host; out_xyz is the MSM over all of them, the
+ * identity iff the proof is valid.  The three index ranges must not overlap. */
+int bp_ipa_verify_msm(bp_ctx* ctx, const bp_bases* bases, size_t g_offset, size_t h_offset,
+                      size_t u_index, const uint64_t* challenges, const uint64_t* challenge_invs,
+                      size_t k, const uint64_t a[4], const uint64_t b[4], const uint64_t u_scalar[4],
+                      const uint64_t* extra_x, const uint64_t* extra_y, const uint8_t* extra_inf,
+                      const uint64_t* extra_scalars, size_t n_extra, uint64_t out_xyz[12]);
 /* out[i] = x^i, i < n: powers_of_x src/poly_commit/mod.rs:16-22, y_vec
  * src/range/aggregate.rs:88-91, hs' scalars src/range/utils.rs:22-29. */
 int bp_powers(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* out);
