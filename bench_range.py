@@ -40,12 +40,14 @@ bgam = rng.integers(0, 1 << 64, (4, m, 4), dtype=np.uint64)
 bgam[:, :, 3] &= np.uint64((1 << 63) - 1)
 host_mirror.range_aggregate_verify_batch(ctx, bp.SECP256K1, gs, hs, ugh, bvals, bgam, n_bits, 8, SEED, SEED + 1)
 vb = host_mirror.range_aggregate_verify_batch(ctx, bp.SECP256K1, gs, hs, ugh, bvals, bgam, n_bits, 100, SEED, SEED + 1)
-assert vb["ok_device"] and vb["ok_host"]
+assert vb["ok_device"] and vb["ok_host"] and vb["ok_direct"]
 out["verify_batch_100"] = {"collect_ms": vb["collect_ms"], "device_merge_ms": vb["device_merge_ms"],
                            "host_merge_ms": vb["host_merge_ms"],
                            "batches_per_s_device_merge": 1e3 / (vb["collect_ms"] + vb["device_merge_ms"]),
                            "proofs_per_s_device_merge": 100e3 / (vb["collect_ms"] + vb["device_merge_ms"]),
                            "proofs_per_s_host_merge": 100e3 / (vb["collect_ms"] + vb["host_merge_ms"]),
+                           "direct_ms": vb["direct_ms"], "proofs_per_s_direct": 100e3 / vb["direct_ms"],
                            "note": "collect = 100 x verify_aux (scalars of the deferred MSM, one at a time on one context); "
-                                   "merge = the random linear combination and its single MSM"}
+                                   "merge = the random linear combination and its single MSM; direct = the whole batch with every proof's "
+                                   "CRS scalars built and added on the device (bp_batch_axpy_range_agg), one MSM"}
 print(json.dumps(out))

@@ -1218,21 +1218,13 @@ int bp_range_agg_verify_scalars(bp_ctx* ctx, int curve, const uint64_t* challeng
   return BP_OK;
 }
 
-int bp_range_agg_verify_msm(bp_ctx* ctx, const bp_bases* bases, const uint64_t* challenges, const uint64_t* challenge_invs,
-                            size_t k, const uint64_t a[4], const uint64_t b[4], const uint64_t y_inv[4], const uint64_t z[4],
-                            size_t m, unsigned n_bits, const uint64_t u_scalar[4], const uint64_t* extra_x,
-                            const uint64_t* extra_y, const uint8_t* extra_inf, const uint64_t* extra_scalars, size_t n_extra,
-                            uint64_t out_xyz[12]) {
-  if (!ctx || !bases || !a || !b || !y_inv || !z || !u_scalar || !out_xyz || (k && (!challenges || !challenge_invs)) ||
-      (n_extra && (!extra_x || !extra_y || !extra_scalars)))
-    return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: null argument");
-  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: bases belong to another context");
-  if (k > 28 || m == 0 || n_bits == 0 || n_bits > 64 || m * (size_t)n_bits != ((size_t)1 << k))
-    return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: m * n_bits must be 2^k");
+namespace {
+// The scalars of gs | hs | u of the aggregated range verifier in one device vector of 2n + 1 elements
+// (S_IN5), n = m * n_bits = 2^k: bp_range_agg_verify_scalars' values and u_scalar behind them.
+int range_verify_dense(bp_ctx* ctx, int curve, const uint64_t* challenges, const uint64_t* challenge_invs, size_t k,
+                       const uint64_t a[4], const uint64_t b[4], const uint64_t y_inv[4], const uint64_t z[4], size_t m,
+                       unsigned n_bits, const uint64_t u_scalar[4], u32** out) {
   const size_t n = (size_t)1 << k;
-  if (bases->n < 2 * n + 1) return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: base set shorter than 2 * m * n_bits + 1");
-  const int curve = bases->curve;
-  Guard g(ctx);
   std::vector<uint64_t> tab(4 * (m + n_bits));
   if (curve == BP_SECP256K1)
     range_tables<Secp256k1Fr>(z, m, n_bits, tab.data(), tab.data() + 4 * m);
@@ -1249,7 +1241,6 @@ int bp_range_agg_verify_msm(bp_ctx* ctx, const bp_bases* bases, const uint64_t* 
   CHK(reserve(ctx, S_OUT0, n * 32, &dss));
   CHK(reserve(ctx, S_OUT1, n * 32, &dssi));
   CHK(reserve(ctx, S_OUT2, n * 32, &dyi));
-  // the scalars of gs | hs | u in one vector, where the MSM reads them
   CHK(reserve(ctx, S_IN5, (2 * n + 1) * 32, &dsc));
   u32* dg = (u32*)dsc;
   u32* dh = dg + n * 8;
@@ -1261,6 +1252,28 @@ int bp_range_agg_verify_msm(bp_ctx* ctx, const bp_bases* bases, const uint64_t* 
                                     (const u32*)dtab + 8 * m, n_bits, n, to_arg(a), to_arg(b), to_arg(z), dg, dh, ctx->stream);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "range_verify_scalars", e);
   HIPCHK(ctx, hipMemcpyAsync(dg + 2 * n * 8, u_scalar, 32, hipMemcpyHostToDevice, ctx->stream));
+  *out = dg;
+  return BP_OK;
+}
+}  // namespace
+
+int bp_range_agg_verify_msm(bp_ctx* ctx, const bp_bases* bases, const uint64_t* challenges, const uint64_t* challenge_invs,
+                            size_t k, const uint64_t a[4], const uint64_t b[4], const uint64_t y_inv[4], const uint64_t z[4],
+                            size_t m, unsigned n_bits, const uint64_t u_scalar[4], const uint64_t* extra_x,
+                            const uint64_t* extra_y, const uint8_t* extra_inf, const uint64_t* extra_scalars, size_t n_extra,
+                            uint64_t out_xyz[12]) {
+  if (!ctx || !bases || !a || !b || !y_inv || !z || !u_scalar || !out_xyz || (k && (!challenges || !challenge_invs)) ||
+      (n_extra && (!extra_x || !extra_y || !extra_scalars)))
+    return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: bases belong to another context");
+  if (k > 28 || m == 0 || n_bits == 0 || n_bits > 64 || m * (size_t)n_bits != ((size_t)1 << k))
+    return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: m * n_bits must be 2^k");
+  const size_t n = (size_t)1 << k;
+  if (bases->n < 2 * n + 1) return fail(ctx, BP_E_ARG, "bp_range_agg_verify_msm: base set shorter than 2 * m * n_bits + 1");
+  const int curve = bases->curve;
+  Guard g(ctx);
+  u32* dsc = nullptr;
+  CHK(range_verify_dense(ctx, curve, challenges, challenge_invs, k, a, b, y_inv, z, m, n_bits, u_scalar, &dsc));
   void *dx = nullptr, *dy = nullptr, *di = nullptr, *des = nullptr;
   if (n_extra) {
     // the slots of the challenges and tables are free again in stream order
@@ -1272,6 +1285,22 @@ int bp_range_agg_verify_msm(bp_ctx* ctx, const bp_bases* bases, const uint64_t* 
   MsmPart p0{bases->x, bases->y, bases->inf, (const u32*)dsc, 2 * n + 1};
   MsmPart p1{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)des, n_extra};
   return msm_full(ctx, curve, p0, p1, out_xyz);
+}
+
+int bp_batch_axpy_range_agg(bp_batch* b, const uint64_t weight[4], const uint64_t* challenges,
+                            const uint64_t* challenge_invs, size_t k, const uint64_t a[4], const uint64_t bb[4],
+                            const uint64_t y_inv[4], const uint64_t z[4], size_t m, unsigned n_bits,
+                            const uint64_t u_scalar[4]) {
+  if (!b || !weight || !a || !bb || !y_inv || !z || !u_scalar || (k && (!challenges || !challenge_invs))) return BP_E_ARG;
+  bp_ctx* ctx = b->ctx;
+  if (k > 28 || m == 0 || n_bits == 0 || n_bits > 64 || m * (size_t)n_bits != ((size_t)1 << k))
+    return fail(ctx, BP_E_ARG, "bp_batch_axpy_range_agg: m * n_bits must be 2^k");
+  const size_t n = (size_t)1 << k;
+  if (b->n < 2 * n + 1) return fail(ctx, BP_E_ARG, "bp_batch_axpy_range_agg: accumulator shorter than 2 * m * n_bits + 1");
+  Guard g(ctx);
+  u32* dsc = nullptr;
+  CHK(range_verify_dense(ctx, b->bases->curve, challenges, challenge_invs, k, a, bb, y_inv, z, m, n_bits, u_scalar, &dsc));
+  return batch_axpy(b, 0, dsc, 2 * n + 1, weight);
 }
 
 int bp_ipa_verify_msm(bp_ctx* ctx, const bp_bases* bases, size_t g_offset, size_t h_offset, size_t u_index,

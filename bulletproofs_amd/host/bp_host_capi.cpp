@@ -411,7 +411,8 @@ template <class Fq, class Fr, int CURVE>
 int range_verify_batch(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx, const uint64_t* hy,
                        const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma, size_t m, unsigned n_bits,
                        uint64_t seed_rand, uint64_t seed_chal, int distinct, int batch, int tamper, double* collect_ms,
-                       double* device_merge_ms, double* host_merge_ms, int* ok_device, int* ok_host) {
+                       double* device_merge_ms, double* host_merge_ms, int* ok_device, int* ok_host, double* direct_ms,
+                       int* ok_direct) {
   using R = RangeAggregate<Fq, Fr, CURVE>;
   using PO = PointOps<Fq, Fr>;
   using M = Msm<Fq, Fr, CURVE>;
@@ -458,6 +459,27 @@ int range_verify_batch(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, cons
   *collect_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
   *device_merge_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
   *host_merge_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+  // the whole batch with every proof's CRS scalars built and added on the device (R::verify_batch): same
+  // proofs, same transcripts, same alpha, hence the same verdict
+  {
+    std::vector<RangeProof> prs(batch);
+    std::vector<SeededTranscript<Fr>> ts;
+    std::vector<SeededRandom<Fr>> rs;
+    ts.reserve(batch); rs.reserve(batch);
+    std::vector<typename R::BatchItem> items(batch);
+    for (int k = 0; k < batch; k++) {
+      const int p = k % distinct;
+      prs[k] = proofs[p];
+      if (tamper && k == batch - 1) prs[k].t_hat = ScalarOps<Fr>::add(prs[k].t_hat, ScalarOps<Fr>::one());
+      ts.emplace_back(seed_chal + p);
+      rs.emplace_back((seed_rand + p) ^ 0x5EEDull);
+    }
+    for (int k = 0; k < batch; k++) items[k] = typename R::BatchItem{&vcoms[k % distinct], &prs[k], &ts[k], &rs[k]};
+    auto t4 = clock::now();
+    *ok_direct = R::verify_batch(ctx, crs, n_bits, items, alpha) ? 1 : 0;
+    auto t5 = clock::now();
+    *direct_ms = std::chrono::duration<double, std::milli>(t5 - t4).count();
+  }
   return 0;
 }
 
@@ -490,17 +512,18 @@ int bph_range_agg_verify_batch(bp_ctx* ctx, int curve, const uint64_t* gx, const
                                const uint64_t* hy, const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma,
                                size_t m, unsigned n_bits, uint64_t seed_rand, uint64_t seed_chal, int distinct, int batch,
                                int tamper, double* collect_ms, double* device_merge_ms, double* host_merge_ms, int* ok_device,
-                               int* ok_host) {
-  if (distinct < 1 || batch < 1) return BP_E_ARG;
+                               int* ok_host, double* direct_ms, int* ok_direct) {
+  if (distinct < 1 || batch < 1 || !direct_ms || !ok_direct) return BP_E_ARG;
   try {
     if (curve == BP_SECP256K1)
       return range_verify_batch<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(ctx, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits,
                                                                        seed_rand, seed_chal, distinct, batch, tamper, collect_ms,
-                                                                       device_merge_ms, host_merge_ms, ok_device, ok_host);
+                                                                       device_merge_ms, host_merge_ms, ok_device, ok_host, direct_ms,
+                                                                       ok_direct);
     if (curve == BP_VESTA)
       return range_verify_batch<VestaFq, VestaFr, BP_VESTA>(ctx, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits, seed_rand,
                                                            seed_chal, distinct, batch, tamper, collect_ms, device_merge_ms,
-                                                           host_merge_ms, ok_device, ok_host);
+                                                           host_merge_ms, ok_device, ok_host, direct_ms, ok_direct);
     return BP_E_CURVE;
   } catch (const std::exception&) {
     return BP_E_HIP;

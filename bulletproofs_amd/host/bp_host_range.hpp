@@ -301,6 +301,49 @@ struct RangeAggregate {
     return is_zero(verify_value(ctx, crs, v_commit, n_bits, pr, t, rng));
   }
 
+  // verify_batch_aux (src/msm.rs:91-115) over aggregated range proofs of one CRS with nothing but the
+  // handful of non-CRS terms on the host: every proof's gs | hs | u scalars are built on the device and
+  // added to the batch accumulator there with the weight alpha^i (bp_batch_axpy_range_agg), the other
+  // terms are scaled and merged in a host accumulator, one MSM finishes.
+  struct BatchItem {
+    const std::vector<Projective>* v_commit;
+    const RangeProof* proof;
+    Transcript* transcript;
+    RandomSource* rng;
+  };
+  static bool verify_batch(bp_ctx* ctx, const Crs& crs, unsigned n_bits, const std::vector<BatchItem>& items,
+                           const Scalar& alpha) {
+    if (items.empty()) throw std::invalid_argument("non-empty vec");
+    const size_t n = crs.n;
+    bp_batch* batch = nullptr;
+    check(ctx, bp_batch_begin(ctx, crs.gh, 2 * n + 1, &batch), "bp_batch_begin");
+    struct Release { bp_batch* b; ~Release() { bp_batch_free(b); } } release{batch};
+    M rest(ctx);
+    Scalar pw = S::one(), dummy = S::one();
+    for (const BatchItem& it : items) {
+      const VerifyPlan vp = verify_plan(crs, *it.v_commit, n_bits, *it.proof, *it.transcript, *it.rng);
+      const size_t k = vp.k;
+      check(ctx, bp_batch_axpy_range_agg(batch, pw.l, k ? vp.xs[0].l : dummy.l, k ? vp.xinv[0].l : dummy.l, k,
+                                         it.proof->ipa.a.l, it.proof->ipa.b.l, vp.y_inv.l, vp.z.l, vp.m, n_bits,
+                                         vp.u_scalar.l),
+            "bp_batch_axpy_range_agg");
+      for (const auto& pt : vp.terms) rest.upsert(pt.first, S::mul(pt.second, pw));
+      pw = S::mul(pw, alpha);
+    }
+    const size_t ne = rest.map().size();
+    std::vector<uint64_t> x(ne * 4 + 4), y(ne * 4 + 4), sc(ne * 4 + 4);
+    std::vector<uint8_t> inf(ne + 1);
+    size_t i = 0;
+    for (auto& kv : rest.map()) {
+      memcpy(&x[4 * i], kv.first.x, 32); memcpy(&y[4 * i], kv.first.y, 32); inf[i] = kv.first.inf;
+      memcpy(&sc[4 * i], kv.second.l, 32);
+      i++;
+    }
+    Projective out;
+    check(ctx, bp_batch_msm(batch, x.data(), y.data(), inf.data(), sc.data(), ne, out.xyz), "bp_batch_msm");
+    return is_zero(out);
+  }
+
   // The same verifier in the reference's order of operations (every intermediate group element
   // computed as there); kept as the cross-check of verify_aux.
   // src/range/aggregate.rs:173-282: returns the deferred MSM that must evaluate to zero.

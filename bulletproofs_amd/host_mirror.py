@@ -122,7 +122,7 @@ def range_aggregate_throughput(device, curve, gs, hs, ugh_xy, values, gamma, n_b
 hlib.bph_range_agg_verify_batch.restype = ci
 hlib.bph_range_agg_verify_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint64, C.c_uint64, ci, ci, ci,
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                            C.POINTER(ci), C.POINTER(ci)]
+                                            C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_double), C.POINTER(ci)]
 
 
 def range_aggregate_verify_batch(ctx: Context, curve, gs, hs, ugh_xy, values, gamma, n_bits, batch, seed_rand=1, seed_chal=2,
@@ -130,7 +130,9 @@ def range_aggregate_verify_batch(ctx: Context, curve, gs, hs, ugh_xy, values, ga
     """verify_batch of the range benches (benches/aggregate_range_bench.rs:65-84): values (distinct, m) and
     gamma (distinct, m, 4) give `distinct` proofs; a batch of `batch` verifications cycling through them is
     collected (verify_aux each) and combined by verify_batch_aux (src/msm.rs:91-115), on the device and on
-    the host.  tamper: the last proof of the batch is corrupted and both combinations must reject."""
+    the host; and once more with every proof's CRS scalars built and added on the device
+    (RangeAggregate::verify_batch: direct_ms, ok_direct).  tamper: the last proof of the batch is corrupted
+    and all three must reject."""
     gx, gy, _ = _pts(gs)
     hx, hy, _ = _pts(hs)
     values = np.ascontiguousarray(values, dtype=np.uint64)
@@ -141,14 +143,14 @@ def range_aggregate_verify_batch(ctx: Context, curve, gs, hs, ugh_xy, values, ga
     assert n & (n - 1) == 0 and gx.shape[0] >= n and hx.shape[0] >= n
     ugh_xy = np.ascontiguousarray(ugh_xy, dtype=np.uint64).reshape(24)
     tc, td, th = C.c_double(), C.c_double(), C.c_double()
-    okd, okh = ci(), ci()
+    okd, okh, okx, tx = ci(), ci(), ci(), C.c_double()
     rc = hlib.bph_range_agg_verify_batch(ctx.h, curve, _p(gx), _p(gy), _p(hx), _p(hy), _p(ugh_xy), _p(values), _p(gamma), m,
                                          n_bits, seed_rand, seed_chal, distinct, batch, int(bool(tamper)), C.byref(tc),
-                                         C.byref(td), C.byref(th), C.byref(okd), C.byref(okh))
+                                         C.byref(td), C.byref(th), C.byref(okd), C.byref(okh), C.byref(tx), C.byref(okx))
     if rc:
         raise RuntimeError(f"bph_range_agg_verify_batch rc={rc}")
-    return dict(ok_device=bool(okd.value), ok_host=bool(okh.value), collect_ms=tc.value, device_merge_ms=td.value,
-                host_merge_ms=th.value)
+    return dict(ok_device=bool(okd.value), ok_host=bool(okh.value), ok_direct=bool(okx.value), collect_ms=tc.value,
+                device_merge_ms=td.value, host_merge_ms=th.value, direct_ms=tx.value)
 
 
 hlib.bph_poly_roundtrip.restype = ci

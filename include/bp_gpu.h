@@ -197,6 +197,15 @@ int bp_batch_begin(bp_ctx* ctx, const bp_bases* bases, size_t n, bp_batch** out)
 int bp_batch_axpy(bp_batch* b, size_t offset, const uint64_t* scalars, size_t count, const uint64_t weight[4]);
 int bp_batch_axpy_dev(bp_batch* b, size_t offset, const uint64_t* d_scalars, size_t count,
                       const uint64_t weight[4]);
+/* One aggregated range proof's share of a batch, built where it is added: acc[0, 2n + 1) +=
+ * weight * (scalars of gs | hs | u as bp_range_agg_verify_msm builds them), n = m * n_bits = 2^k.
+ * The accumulator must cover the CRS layout gs | hs | u (bp_batch_begin with n >= 2 * m * n_bits + 1).
+ * The proof's other terms (A, S, T1, T2, V_j, L_j, R_j, g, h) go to bp_batch_msm as extras, scaled by
+ * the caller (verify_batch_aux, src/msm.rs:91-115). */
+int bp_batch_axpy_range_agg(bp_batch* b, const uint64_t weight[4], const uint64_t* challenges,
+                            const uint64_t* challenge_invs, size_t k, const uint64_t a[4],
+                            const uint64_t bb[4], const uint64_t y_inv[4], const uint64_t z[4], size_t m,
+                            unsigned n_bits, const uint64_t u_scalar[4]);
 int bp_batch_msm(bp_batch* b, const uint64_t* extra_x, const uint64_t* extra_y, const uint8_t* extra_inf,
                  const uint64_t* extra_scalars, size_t n_extra, uint64_t out_xyz[12]);
 void bp_batch_free(bp_batch* b);

@@ -156,9 +156,9 @@ def test_range_proof_batch_verification_on_the_device(ctx, coracle, c):
     ugh = np.stack([np.concatenate([o.pack_field([P[0]], c.p)[0], o.pack_field([P[1]], c.p)[0]]) for P in (u, g, h)])
     G, H = o.pack_points(gs, c), o.pack_points(hs, c)
     good = host_mirror.range_aggregate_verify_batch(ctx, c.id, G, H, ugh, values, gammas, n_bits, 10, 5, 6)
-    assert good["ok_device"] and good["ok_host"]
+    assert good["ok_device"] and good["ok_host"] and good["ok_direct"]
     bad = host_mirror.range_aggregate_verify_batch(ctx, c.id, G, H, ugh, values, gammas, n_bits, 10, 5, 6, tamper=True)
-    assert not bad["ok_device"] and not bad["ok_host"]
+    assert not bad["ok_device"] and not bad["ok_host"] and not bad["ok_direct"]
 
     # the primitives: three weighted scalar vectors over 300 registered points plus two outside points
     npts = 300
