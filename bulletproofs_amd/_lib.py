@@ -94,6 +94,7 @@ SIGNATURES = {
     "bp_range_agg_poly": (ci, [vp, ci, vp, sz, C.c_uint, vp, vp, vp, vp, vp, vp]),
     "bp_range_agg_eval": (ci, [vp, ci, vp, sz, vp, vp, vp]),
     "bp_range_agg_verify_scalars": (ci, [vp, ci, vp, vp, sz, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
+    "bp_batch_axpy_ipa": (ci, [vp, vp, sz, sz, sz, vp, vp, sz, vp, vp, vp]),
     "bp_batch_axpy_range_agg": (ci, [vp, vp, vp, vp, sz, vp, vp, vp, vp, sz, C.c_uint, vp]),
     "bp_ipa_verify_msm": (ci, [vp, vp, sz, sz, sz, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "bp_range_agg_verify_msm": (ci, [vp, vp, vp, vp, sz, vp, vp, vp, vp, sz, C.c_uint, vp, vp, vp, vp, vp, sz, vp]),

@@ -100,6 +100,10 @@ struct bp_ctx {
   // takes a round's two inner products writes them there as well, so no copy command follows the MSM
   void* host_slots = nullptr;
   uint64_t host_slots_free = ~0ull;
+  // pinned ring for the small host arguments of calls that return before their launches have run
+  // (stage_h2d): the caller's buffers are free on return whatever the runtime does with pageable memory
+  char* stage = nullptr;
+  size_t stage_off = 0;
   hipEvent_t ev[6] = {};
   int c_override = 0;
   float last_ms[3] = {0, 0, 0};
@@ -139,6 +143,9 @@ struct bp_batch {
   size_t n;
   u32* acc;
 };
+
+// size of a context's pinned staging ring (stage_h2d)
+constexpr size_t kStageBytes = (size_t)1 << 20;
 
 // sessions over at least this many generators replace them by the folded ones every few rounds
 constexpr size_t kIpaRebaseMinPoints = (size_t)1 << 15;
@@ -251,6 +258,27 @@ int reserve_pinned(bp_ctx* ctx, size_t bytes) {
   size_t want = (bytes + 65535) & ~(size_t)65535;
   HIPCHK(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
   ctx->pinned_cap = want;
+  return BP_OK;
+}
+
+// Host bytes to the device through the context's pinned ring: copied into the ring now, from the ring
+// to `dst` in stream order.  The ring is reused only after the stream has drained, so a call may
+// return before its launches have run and its host arguments (locals included) may go out of scope.
+int stage_h2d(bp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return BP_OK;
+  const size_t al = (bytes + 63) & ~(size_t)63;
+  if (al > kStageBytes) {  // too large for the ring: copy and wait
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BP_OK;
+  }
+  if (ctx->stage_off + al > kStageBytes) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stage_off = 0;
+  }
+  memcpy(ctx->stage + ctx->stage_off, src, bytes);
+  HIPCHK(ctx, hipMemcpyAsync(dst, ctx->stage + ctx->stage_off, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ctx->stage_off += al;
   return BP_OK;
 }
 
@@ -442,6 +470,11 @@ int bp_init(int device, bp_ctx** out) {
     bp_shutdown(c);
     return BP_E_HIP;
   }
+  if (hipHostMalloc((void**)&c->stage, kStageBytes, hipHostMallocDefault) != hipSuccess) {
+    c->stage = nullptr;
+    bp_shutdown(c);
+    return BP_E_HIP;
+  }
   // address of this device's copy of the static scratch array (the device is current: hipSetDevice above)
   {
     void* p = nullptr;
@@ -463,6 +496,7 @@ void bp_shutdown(bp_ctx* ctx) {
     if (b.p) (void)hipFree(b.p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->host_slots) (void)hipHostFree(ctx->host_slots);
+  if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->ipa_cache) (void)hipFree(ctx->ipa_cache);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1230,12 +1264,16 @@ int range_verify_dense(bp_ctx* ctx, int curve, const uint64_t* challenges, const
     range_tables<Secp256k1Fr>(z, m, n_bits, tab.data(), tab.data() + 4 * m);
   else
     range_tables<VestaFr>(z, m, n_bits, tab.data(), tab.data() + 4 * m);
+  // host arguments go through the staging ring: bp_batch_axpy_range_agg returns before the launches run
   void *dch = nullptr, *dchi = nullptr, *dtab, *dt, *dss, *dssi, *dyi, *dsc;
   if (k) {
-    CHK(upload(ctx, S_IN0, challenges, k * 32, &dch));
-    CHK(upload(ctx, S_IN1, challenge_invs, k * 32, &dchi));
+    CHK(reserve(ctx, S_IN0, k * 32, &dch));
+    CHK(reserve(ctx, S_IN1, k * 32, &dchi));
+    CHK(stage_h2d(ctx, dch, challenges, k * 32));
+    CHK(stage_h2d(ctx, dchi, challenge_invs, k * 32));
   }
-  CHK(upload(ctx, S_IN2, tab.data(), tab.size() * 8, &dtab));
+  CHK(reserve(ctx, S_IN2, tab.size() * 8, &dtab));
+  CHK(stage_h2d(ctx, dtab, tab.data(), tab.size() * 8));
   size_t te = s_vector_table_elems((int)k), pe = powers_table_elems(n);
   CHK(reserve(ctx, S_TABLE, (te > pe ? te : pe) * 32, &dt));
   CHK(reserve(ctx, S_OUT0, n * 32, &dss));
@@ -1251,7 +1289,7 @@ int range_verify_dense(bp_ctx* ctx, int curve, const uint64_t* challenges, const
     e = launch_range_verify_scalars(curve, (const u32*)dss, (const u32*)dssi, (const u32*)dyi, (const u32*)dtab,
                                     (const u32*)dtab + 8 * m, n_bits, n, to_arg(a), to_arg(b), to_arg(z), dg, dh, ctx->stream);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "range_verify_scalars", e);
-  HIPCHK(ctx, hipMemcpyAsync(dg + 2 * n * 8, u_scalar, 32, hipMemcpyHostToDevice, ctx->stream));
+  CHK(stage_h2d(ctx, dg + 2 * n * 8, u_scalar, 32));
   *out = dg;
   return BP_OK;
 }
@@ -1301,6 +1339,53 @@ int bp_batch_axpy_range_agg(bp_batch* b, const uint64_t weight[4], const uint64_
   u32* dsc = nullptr;
   CHK(range_verify_dense(ctx, b->bases->curve, challenges, challenge_invs, k, a, bb, y_inv, z, m, n_bits, u_scalar, &dsc));
   return batch_axpy(b, 0, dsc, 2 * n + 1, weight);
+}
+
+int bp_batch_axpy_ipa(bp_batch* b, const uint64_t weight[4], size_t g_offset, size_t h_offset, size_t u_index,
+                      const uint64_t* challenges, const uint64_t* challenge_invs, size_t k, const uint64_t a[4],
+                      const uint64_t bb[4], const uint64_t u_scalar[4]) {
+  if (!b || !weight || !a || !bb || !u_scalar || (k && (!challenges || !challenge_invs))) return BP_E_ARG;
+  bp_ctx* ctx = b->ctx;
+  if (k > 28) return fail(ctx, BP_E_ARG, "bp_batch_axpy_ipa: too many rounds");
+  const size_t n = (size_t)1 << k, nb = b->n;
+  if (g_offset > nb || n > nb - g_offset || h_offset > nb || n > nb - h_offset || u_index >= nb)
+    return fail(ctx, BP_E_ARG, "bp_batch_axpy_ipa: range outside the accumulator");
+  const int curve = b->bases->curve;
+  // weight * a, weight * b, weight * u_scalar (Montgomery products on the host)
+  uint64_t wa[4], wb[4], wu[4];
+  {
+    host::HFe hw, ha, hb, hu;
+    memcpy(hw.v, weight, 32); memcpy(ha.v, a, 32); memcpy(hb.v, bb, 32); memcpy(hu.v, u_scalar, 32);
+    host::HFe ra, rb, ru;
+    if (curve == BP_SECP256K1) {
+      ra = host::h_mul<Secp256k1Fr>(hw, ha); rb = host::h_mul<Secp256k1Fr>(hw, hb); ru = host::h_mul<Secp256k1Fr>(hw, hu);
+    } else {
+      ra = host::h_mul<VestaFr>(hw, ha); rb = host::h_mul<VestaFr>(hw, hb); ru = host::h_mul<VestaFr>(hw, hu);
+    }
+    memcpy(wa, ra.v, 32); memcpy(wb, rb.v, 32); memcpy(wu, ru.v, 32);
+  }
+  Guard g(ctx);
+  void *dch = nullptr, *dchi = nullptr, *dt, *dtmp;
+  if (k) {
+    CHK(reserve(ctx, S_IN0, k * 32, &dch));
+    CHK(reserve(ctx, S_IN1, k * 32, &dchi));
+    CHK(stage_h2d(ctx, dch, challenges, k * 32));
+    CHK(stage_h2d(ctx, dchi, challenge_invs, k * 32));
+  }
+  CHK(reserve(ctx, S_TABLE, s_vector_table_elems((int)k) * 32, &dt));
+  // acc[gs] += (weight a) s, acc[hs] += (weight b) s^-1   (src/ipa/mod.rs:134-166 under src/msm.rs:91-115)
+  hipError_t e = launch_s_vector_axpy(curve, (const u32*)dch, (const u32*)dchi, (int)k, to_arg(wa), 0, (u32*)dt,
+                                      b->acc + g_offset * 8, ctx->stream);
+  if (e == hipSuccess)
+    e = launch_s_vector_axpy(curve, (const u32*)dchi, (const u32*)dch, (int)k, to_arg(wb), 0, (u32*)dt, b->acc + h_offset * 8,
+                             ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "s_vector_axpy", e);
+  // acc[u] += weight * u_scalar
+  CHK(reserve(ctx, S_IN2, 32, &dtmp));
+  CHK(stage_h2d(ctx, dtmp, wu, 32));
+  e = launch_vec_op(curve, BP_VEC_ADD, b->acc + u_index * 8, (const u32*)dtmp, FeArg{}, 1, b->acc + u_index * 8, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "bp_batch_axpy_ipa", e);
+  return BP_OK;
 }
 
 int bp_ipa_verify_msm(bp_ctx* ctx, const bp_bases* bases, size_t g_offset, size_t h_offset, size_t u_index,

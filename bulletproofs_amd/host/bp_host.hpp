@@ -528,6 +528,58 @@ struct Ipa {
     return out;
   }
 
+  // verify_batch_aux (src/msm.rs:91-115) over inner-product arguments of one registered CRS with the CRS
+  // part of every accumulator built and added on the device (bp_batch_axpy_ipa); P, L_j, R_j are scaled
+  // and merged in a host accumulator, one MSM finishes.
+  struct BatchItem {
+    const Projective* p;
+    const IpaProof* proof;
+    Transcript* transcript;
+  };
+  static bool verify_batch_resident(bp_ctx* ctx, const bp_bases* bases, size_t n_bases, size_t g_off, size_t h_off,
+                                    size_t u_index, size_t n, const std::vector<BatchItem>& items, const Scalar& alpha) {
+    if (items.empty()) throw std::invalid_argument("non-empty vec");
+    bp_batch* batch = nullptr;
+    check(ctx, bp_batch_begin(ctx, bases, n_bases, &batch), "bp_batch_begin");
+    struct Release { bp_batch* b; ~Release() { bp_batch_free(b); } } release{batch};
+    Msm<Fq, Fr, CURVE> rest(ctx);
+    Scalar pw = S::one(), dummy = S::one(), minus_one = S::neg(S::one());
+    for (const BatchItem& it : items) {
+      const IpaProof& proof = *it.proof;
+      const size_t k = checked_rounds(proof.L.size(), proof.R.size(), n);
+      std::vector<Scalar> xs(k), xinv(k);
+      for (size_t j = 0; j < k; j++) {
+        Projective lr[2] = {proof.L[j], proof.R[j]};
+        it.transcript->prover_points(lr, 2);
+        xs[j] = it.transcript->verifier_scalar();
+      }
+      S::batch_inv(xs, xinv);
+      Scalar ab = S::mul(proof.a, proof.b);
+      check(ctx, bp_batch_axpy_ipa(batch, pw.l, g_off, h_off, u_index, k ? xs[0].l : dummy.l, k ? xinv[0].l : dummy.l, k,
+                                   proof.a.l, proof.b.l, ab.l),
+            "bp_batch_axpy_ipa");
+      Scalar mw = S::mul(minus_one, pw);
+      rest.upsert(P::to_affine(*it.p), mw);
+      for (size_t j = 0; j < k; j++) {
+        rest.upsert(P::to_affine(proof.L[j]), S::mul(mw, S::mul(xs[j], xs[j])));
+        rest.upsert(P::to_affine(proof.R[j]), S::mul(mw, S::mul(xinv[j], xinv[j])));
+      }
+      pw = S::mul(pw, alpha);
+    }
+    const size_t ne = rest.map().size();
+    std::vector<uint64_t> x(ne * 4 + 4), y(ne * 4 + 4), sc(ne * 4 + 4);
+    std::vector<uint8_t> inf(ne + 1);
+    size_t i = 0;
+    for (auto& kv : rest.map()) {
+      memcpy(&x[4 * i], kv.first.x, 32); memcpy(&y[4 * i], kv.first.y, 32); inf[i] = kv.first.inf;
+      memcpy(&sc[4 * i], kv.second.l, 32);
+      i++;
+    }
+    Projective out;
+    check(ctx, bp_batch_msm(batch, x.data(), y.data(), inf.data(), sc.data(), ne, out.xyz), "bp_batch_msm");
+    return is_zero(out);
+  }
+
   // ipa::verify_aux, src/ipa/mod.rs:102-193; challenges are re-derived from the transcript
   static Msm<Fq, Fr, CURVE> verify_aux(bp_ctx* ctx, const Crs& crs, const Projective& p, size_t n, const IpaProof& proof,
                                        Transcript& t) {

@@ -89,6 +89,8 @@ int ipa_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uin
   }
   struct Release { bp_bases* b; ~Release() { bp_bases_free(b); } } release{gh};
   std::vector<Msm<Fq, Fr, CURVE>> msms;
+  std::vector<Projective> batch_p;
+  std::vector<IpaProof> batch_proofs;
   *single_ok = 1;
   for (size_t pi = 0; pi < n_proofs; pi++) {
     auto wa = unpack_s(a + 4 * n * pi, n), wb = unpack_s(b + 4 * n * pi, n);
@@ -137,9 +139,22 @@ int ipa_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uin
         throw std::runtime_error("verifier with device-resident scalars and accumulator verifier disagree");
     }
     msms.push_back(std::move(m));
+    batch_p.push_back(p);
+    batch_proofs.push_back(proof);
   }
   SeededTranscript<Fr> ta(seed ^ 0xA1FAull);
-  *batch_ok = verify_batch_aux(msms, ta.verifier_scalar()) ? 1 : 0;
+  const Scalar alpha = ta.verifier_scalar();
+  // the batch with the CRS part of every accumulator built and added on the device reaches the same verdict
+  {
+    std::vector<SeededTranscript<Fr>> ts;
+    ts.reserve(n_proofs);
+    std::vector<typename I::BatchItem> items(n_proofs);
+    for (size_t pi = 0; pi < n_proofs; pi++) ts.emplace_back(seed + 1000 * pi);
+    for (size_t pi = 0; pi < n_proofs; pi++) items[pi] = typename I::BatchItem{&batch_p[pi], &batch_proofs[pi], &ts[pi]};
+    const bool direct = I::verify_batch_resident(ctx, gh, 2 * n + 1, 0, n, 2 * n, n, items, alpha);
+    *batch_ok = verify_batch_aux(msms, alpha) ? 1 : 0;
+    if (direct != (*batch_ok != 0)) throw std::runtime_error("device-side batch and accumulator batch disagree");
+  }
   return 0;
 }
 

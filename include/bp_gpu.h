@@ -206,6 +206,13 @@ int bp_batch_axpy_range_agg(bp_batch* b, const uint64_t weight[4], const uint64_
                             const uint64_t* challenge_invs, size_t k, const uint64_t a[4],
                             const uint64_t bb[4], const uint64_t y_inv[4], const uint64_t z[4], size_t m,
                             unsigned n_bits, const uint64_t u_scalar[4]);
+/* One inner-product argument's share of a batch, built where it is added: acc[g_offset, +2^k) +=
+ * weight * a * s, acc[h_offset, +2^k) += weight * b * s^-1 (the s-vectors of the challenges and of
+ * their inverses), acc[u_index] += weight * u_scalar: the CRS part of ipa::verify_aux's accumulator
+ * (src/ipa/mod.rs:125-166) under verify_batch_aux's scaling (src/msm.rs:91-115).  Enqueue only. */
+int bp_batch_axpy_ipa(bp_batch* b, const uint64_t weight[4], size_t g_offset, size_t h_offset,
+                      size_t u_index, const uint64_t* challenges, const uint64_t* challenge_invs,
+                      size_t k, const uint64_t a[4], const uint64_t bb[4], const uint64_t u_scalar[4]);
 int bp_batch_msm(bp_batch* b, const uint64_t* extra_x, const uint64_t* extra_y, const uint8_t* extra_inf,
                  const uint64_t* extra_scalars, size_t n_extra, uint64_t out_xyz[12]);
 void bp_batch_free(bp_batch* b);
