@@ -867,3 +867,63 @@ def test_ipa_session_with_powers_built_on_the_device(ctx, c, n):
         _, _, A, B = s.read()
         assert o.unpack_field(A, c.n) == a2 and o.unpack_field(B, c.n) == b2
     s.free()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("layout", ["gs|hs|u", "hs|gap|gs|gap|u"])
+def test_ipa_verify_msm_against_the_oracle(ctx, c, layout):
+    """bp_ipa_verify_msm: sum a s_i G_i + b s_i^-1 H_i + u_scalar U + extras (src/ipa/mod.rs:125-190) with the
+    s-vectors built on the device, against the oracle's s-vector and naive MSM; also with gs, hs, u apart"""
+    k, n = 4, 16
+    rng = o.SplitMix64(0x1FA + c.id + len(layout))
+    pts = o.gen_points_arith(2 * n + 8, rng.field(c.n), rng.field(c.n), c)
+    g, h, u, extra_pts = pts[:n], pts[n:2 * n], pts[2 * n], pts[2 * n + 1:2 * n + 4]
+    pad = pts[2 * n + 4:2 * n + 8]
+    if layout == "gs|hs|u":
+        all_pts, g_off, h_off, u_idx = g + h + [u], 0, n, 2 * n
+    else:
+        all_pts, g_off, h_off, u_idx = h + pad[:2] + g + pad[2:] + [u], n + 2, 0, 2 * n + 4
+    ch = [rng.field(c.n) or 1 for _ in range(k)]
+    chi = [pow(x, -1, c.n) for x in ch]
+    a, b, us = rng.field(c.n), rng.field(c.n), rng.field(c.n)
+    es = rng.scalars(3, c.n)
+    bases = ctx.register_bases(c.id, o.pack_points(all_pts, c))
+    got = bases.ipa_verify_msm(g_off, h_off, u_idx, o.pack_field(ch, c.n), o.pack_field(chi, c.n), o.pack_field([a], c.n),
+                               o.pack_field([b], c.n), o.pack_field([us], c.n), o.pack_points(extra_pts, c),
+                               o.pack_field(es, c.n))
+    s = o.s_vector(ch, c.n)
+    si = o.s_vector(chi, c.n)
+    assert si == [pow(v, -1, c.n) for v in s]
+    scalars = [a * v % c.n for v in s] + [b * v % c.n for v in si] + [us] + es
+    assert xyz_to_affine(got, c) == o.msm_naive(g + h + [u] + extra_pts, scalars, c)
+    bases.free()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+def test_range_agg_verify_msm_against_the_two_step_form(ctx, c):
+    """bp_range_agg_verify_msm equals bp_range_agg_verify_scalars (checked against the big-integer restatement
+    elsewhere) followed by the oracle's MSM over gs | hs | u and the extra terms"""
+    from bulletproofs_amd._lib import lib
+
+    m, n_bits, k = 2, 8, 4
+    n = m * n_bits
+    rng = o.SplitMix64(0x2A66 + c.id)
+    pts = o.gen_points_arith(2 * n + 4, rng.field(c.n), rng.field(c.n), c)
+    crs, extra_pts = pts[:2 * n + 1], pts[2 * n + 1:]
+    ch = [rng.field(c.n) or 1 for _ in range(k)]
+    chi = [pow(x, -1, c.n) for x in ch]
+    a, b, y_inv, z, us = (rng.field(c.n) for _ in range(5))
+    es = rng.scalars(3, c.n)
+    F = lambda v: o.pack_field(v if isinstance(v, list) else [v], c.n)  # noqa: E731
+    gsc, hsc = ctx.range_agg_verify_scalars(c.id, F(ch), F(chi), F(a), F(b), F(y_inv), F(z), m, n_bits)
+    bases = ctx.register_bases(c.id, o.pack_points(crs, c))
+    ex, ey, ei = o.pack_points(extra_pts, c)
+    out = np.zeros(12, dtype=np.uint64)
+    CH, CHI, A, B, YI, Z, US, ES = F(ch), F(chi), F(a), F(b), F(y_inv), F(z), F(us), F(es)
+    rc = lib.bp_range_agg_verify_msm(ctx.h, bases.h, CH.ctypes.data, CHI.ctypes.data, k, A.ctypes.data, B.ctypes.data,
+                                     YI.ctypes.data, Z.ctypes.data, m, n_bits, US.ctypes.data, ex.ctypes.data, ey.ctypes.data,
+                                     ei.ctypes.data, ES.ctypes.data, 3, out.ctypes.data)
+    assert rc == 0
+    scalars = o.unpack_field(gsc, c.n) + o.unpack_field(hsc, c.n) + [us] + es
+    assert xyz_to_affine(out, c) == o.msm_naive(crs + extra_pts, scalars, c)
+    bases.free()
