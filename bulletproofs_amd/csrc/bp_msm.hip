@@ -2283,10 +2283,12 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
   const u32 idx_mask = (1u << plan.wshift) - 1u;
   if (ev_acc0 && (e = hipEventRecord(ev_acc0, st)) != hipSuccess) return e;
   if (plan.small || plan.mid) {
-    // lanes per bucket: as many as keep the launch at about one wave per SIMD, and at least
-    // one per 32 expected entries
+    // lanes per bucket: as many as keep the launch at about one wave per SIMD (two on the
+    // sliced-sort path, whose launches are bound by their work rather than their chain: 2^16 points
+    // 0.209 -> 0.170 ms, no change at 2^17 where the next rule asks for as many anyway; four waves per
+    // SIMD lose again, 0.25 ms), and at least one per 32 expected entries
     int lanes = 64;
-    size_t lane_cap = 65536;
+    size_t lane_cap = plan.mid ? 131072 : 65536;
     if (const char* ev = getenv("BP_MSM_TREE_LANES")) lane_cap = (size_t)atol(ev);  // tuning runs
     while (lanes > 1 && nbt * (size_t)lanes > lane_cap) lanes >>= 1;
     const size_t per_bucket = plan.entries / (nbt ? nbt : 1);
