@@ -77,7 +77,9 @@ static inline int ilog2_floor(size_t n) {
 // points into 2^(t-1) buckets, which then need a deep tree of partial sums.
 int msm_choose_window(size_t n) {
   int l = ilog2_floor(n ? n : 1);
-  if (l >= 18) return 16;
+  // 16-bit windows from 2^17 points: measured 0.41 ms against 0.49 with 8-bit windows at 2^17,
+  // 0.38 against 0.31 at 2^16 (device phase, secp256k1)
+  if (l >= 17) return 16;
   if (l >= 9) return 8;
   return 4;
 }

@@ -28,7 +28,7 @@ def raw_scalars(c, n, seed):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=ids)
-@pytest.mark.parametrize("n,world", [(1023, 2), (3, 4), (4096, 8), ((1 << 19) - 1, 2), (1 << 20, 8)])
+@pytest.mark.parametrize("n,world", [(1023, 2), (3, 4), (4096, 8), ((1 << 18) - 1, 2), ((1 << 19) - 1, 2), (1 << 20, 8)])
 def test_shards_at_the_common_width_add_up(ctx, coracle, c, n, world):
     """shard sizes on both sides of a width threshold (512 | 511 and 2^18 | 2^18 - 1), empty shards
     (3 points over 4 ranks) and the eight-way split of the headline size"""

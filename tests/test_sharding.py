@@ -27,13 +27,13 @@ def test_shard_ranges_cover():
 
 def test_shard_window_width_is_a_function_of_the_total_alone():
     """every rank derives the same width without talking to the others, also where the shard
-    sizes straddle a threshold of the single-GPU choice (511 | 512, 2^18 - 1 | 2^18)"""
+    sizes straddle a threshold of the single-GPU choice (511 | 512, 2^17 - 1 | 2^17)"""
     from bulletproofs_amd.api import shard_window_bits
 
     assert shard_window_bits(1 << 20, 1) == 16
     assert shard_window_bits(1 << 21, 8) == 16
-    assert shard_window_bits((1 << 19) - 1, 2) == 16   # shards of 2^18 and 2^18 - 1 points
-    assert shard_window_bits((1 << 19) - 2, 2) == 8
+    assert shard_window_bits((1 << 18) - 1, 2) == 16   # shards of 2^17 and 2^17 - 1 points
+    assert shard_window_bits((1 << 18) - 2, 2) == 8
     assert shard_window_bits(1023, 2) == 8             # shards of 512 and 511 points
     assert shard_window_bits(1022, 2) == 4
     assert shard_window_bits(3, 4) == 4                # some shards are empty
