@@ -90,11 +90,70 @@ def gen_points_on_gpu(ctx, n, rank):
     return ox, oy
 
 
-def other_configs(ctx, px, py):
+def _oracle_and_cores():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+
+    co = c_oracle.COracle()
+    # the GPU box exposes the whole machine's CPUs; its share is OMP_NUM_THREADS (16 there)
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    return co, max(1, min(cores, co.max_threads()))
+
+
+def cpu_ipa_baseline(G, H, u_xy, wa, wb, samples=3):
+    """C oracle's ipa::prove and ipa::verify (oracle/bp_oracle_proto.c) at the size of config 3 on the
+    host cores: the CPU figure beside other_configs.ipa_2_16.  A C restatement, not the arkworks binary."""
+    co, cores = _oracle_and_cores()
+    n = wa.shape[0]
+    P = co.ipa_statement(0, G, H, u_xy, wa, wb, threads=cores)
+    tp, tv = [], []
+    for _ in range(samples):
+        t0 = time.perf_counter()
+        pr = co.ipa_prove(0, G, H, u_xy, wa, wb, SEED, threads=cores)
+        t1 = time.perf_counter()
+        res = co.ipa_verify(0, G, H, u_xy, P, n, pr["L"], pr["R"], pr["a"], pr["b"], SEED, threads=cores)
+        t2 = time.perf_counter()
+        if res[8:].any():
+            raise SystemExit("C oracle rejected its own inner-product argument")
+        tp.append(t1 - t0)
+        tv.append(t2 - t1)
+    mp, mv = float(np.median(tp)), float(np.median(tv))
+    return dict(prove_ms=mp * 1e3, verify_ms=mv * 1e3, proofs_per_s=1.0 / mp, verifies_per_s=1.0 / mv, cores=cores, kind="port",
+                sample=f"median of {samples} prove + verify runs at n = 2^{n.bit_length() - 1} (prove min {min(tp):.3f} s, max "
+                       f"{max(tp):.3f} s), C restatement of src/ipa/mod.rs:19-212 (oracle/bp_oracle_proto.c, OpenMP inside the MSMs "
+                       f"and folds); not the arkworks binary")
+
+
+def cpu_poly_baseline(G, hg, coeffs, r, x, samples=1):
+    """C oracle's poly_commit::prove and verify at the size of config 5 on the host cores, once each (a
+    prove is several seconds of CPU work): the CPU figure beside other_configs.poly_commit_2_20."""
+    co, cores = _oracle_and_cores()
+    n = coeffs.shape[0]
+    com, ev = co.poly_statement(0, G, hg, coeffs, r, x, threads=cores)
+    tp, tv = [], []
+    for _ in range(samples):
+        t0 = time.perf_counter()
+        pr = co.poly_prove(0, G, hg, coeffs, r, x, SEED, SEED + 1, threads=cores)
+        t1 = time.perf_counter()
+        res, _ = co.poly_verify(0, G, hg, com, x, ev, pr["L"], pr["R"], pr["a"], pr["r"], SEED + 1, threads=cores)
+        t2 = time.perf_counter()
+        if res[8:].any():
+            raise SystemExit("C oracle rejected its own polynomial-commitment opening")
+        tp.append(t1 - t0)
+        tv.append(t2 - t1)
+    mp, mv = float(np.median(tp)), float(np.median(tv))
+    return dict(prove_ms=mp * 1e3, verify_ms=mv * 1e3, cores=cores, kind="port",
+                sample=f"{samples} prove + verify run(s) at n = 2^{n.bit_length() - 1}, C restatement of "
+                       f"src/poly_commit/mod.rs:45-173 (oracle/bp_oracle_proto.c, OpenMP inside the MSMs and folds; the prover "
+                       f"includes the full-size MSM of :108-113 as the reference's does); not the arkworks binary")
+
+
+def other_configs(ctx, px, py, cpu=True):
     """BASELINE configs 3 and 5 beside the headline figure, on the points of the MSM leg: the rounds of
     an inner-product argument over 2 x 2^16 generators (benches/ipa_bench.rs:102-105, seeded challenges)
     and a polynomial-commitment opening of degree 2^20 - 1 with its verification and the fold of two
-    deferred checks (benches/poly_commit_bench.rs), each through the C++ drivers / the session API."""
+    deferred checks (benches/poly_commit_bench.rs), each through the C++ drivers / the session API, and
+    beside each the C oracle's prover and verifier timed on the host cores."""
     import bulletproofs_amd as bp
     from bulletproofs_amd import host_mirror
 
@@ -147,10 +206,14 @@ def other_configs(ctx, px, py):
             valid = valid and not value[8:12].any()
             vbest = dt if vbest is None else min(vbest, dt)
         bases.free()
+        if not valid:
+            raise SystemExit("inner-product argument at n = 2^16 failed to verify")
         out["ipa_2_16"] = {"workload": "inner-product argument, n = 2^16 (2 x 2^16 generators), 16 rounds, seeded challenges; "
                                        "verification as one deferred MSM with its scalars built on the device",
                            "prove_rounds_ms": best * 1e3, "proofs_per_s": 1.0 / best, "verify_ms": vbest * 1e3,
                            "verifies_per_s": 1.0 / vbest, "verified": bool(valid)}
+        if cpu:
+            out["ipa_2_16"]["cpu_baseline"] = cpu_ipa_baseline((px[:n], py[:n], None), (px[n:2 * n], py[n:2 * n], None), u_xy, wa, wb)
     n = px.shape[0]
     if n >= 1 << 20:
         n = 1 << 20
@@ -161,21 +224,79 @@ def other_configs(ctx, px, py):
         coeffs, r, x = rand_field(n), rand_field(1), rand_field(1)
         host_mirror.poly_commit_roundtrip(ctx, C, gs, hg, coeffs, r, x, SEED, SEED + 1, halo=False)  # warm-up
         res = host_mirror.poly_commit_roundtrip(ctx, C, gs, hg, coeffs, r, x, SEED, SEED + 1, halo=True)
+        if not (res["verify_ok"] and res["lazy_ok"] and res["halo_ok"]):
+            raise SystemExit("polynomial-commitment opening at degree 2^20 - 1 failed to verify")
         out["poly_commit_2_20"] = {"workload": "polynomial commitment opening, degree 2^20 - 1, CRS resident",
                                    "prove_ms": res["prove_ms"], "verify_ms": res["verify_ms"],
                                    "all_verified": bool(res["verify_ok"] and res["lazy_ok"] and res["halo_ok"])}
+        if cpu:
+            out["poly_commit_2_20"]["cpu_baseline"] = cpu_poly_baseline(gs, hg, coeffs, r[0], x[0])
+    return out
+
+
+# Memory-side bytes of the streaming kernels at 2^24 elements from separate `rocprofv3 --pmc FETCH_SIZE` /
+# `--pmc WRITE_SIZE` runs of tools/stream_kernels.py (tools/prof_stream.sh; FETCH_SIZE doubled as coalesced
+# 16-byte-per-lane reads on gfx950 require): read + written bytes per launch, profiles/r02_v5_stream_pmc_summary.csv
+PMC_STREAM_2_24 = {"fold_scalars": 1124257587 + 607618253, "inner_product": 1278147584 + 32768, "s_vector": 8525824 + 571458150}
+HBM_PEAK_GBPS = 8000.0
+
+
+def streaming_kernels(ctx, torch):
+    """fold_scalars (src/ipa/mod.rs:229-234), inner_product (src/vector_ops.rs:159-171) and the s-vector
+    (src/ipa/mod.rs:134-148) at 2^20 and 2^24 elements, inputs resident in HBM: algorithmic bytes per
+    element (96 / 64 / 32) over the HIP-event duration of the launch(es), best of five, against the 8 TB/s
+    of HBM3E.  At 2^20 elements (32-96 MB, the size BASELINE's configurations use) a launch is some 25 us
+    and what is measured is launch latency, not memory."""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd._lib import lib
+
+    C = bp.SECP256K1
+    rng = np.random.default_rng(SEED + 5)
+
+    def rand_field(cnt):
+        a = rng.integers(0, 1 << 64, (cnt, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 63) - 1)
+        return a
+
+    def best(fn, reps=5):
+        fn()
+        ts = []
+        for _ in range(reps):
+            fn()
+            ts.append(ctx.last_kernel_ms(2))
+        return min(ts)
+
+    out = {"peak_GBps": HBM_PEAK_GBPS, "bound": "hbm (nominal 8 TB/s); the field multiply per element keeps fold_scalars and "
+                                                "inner_product near 0.6 of it and the s-vector, one product per 32 bytes, near 0.35",
+           "traffic_source": "profiles/r02_v5_stream_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)"}
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()  # noqa: E731
+    for logn in (20, 24):
+        n = 1 << logn
+        a, b = to_dev(rand_field(n)), to_dev(rand_field(n))
+        o = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+        x, y = rand_field(1), rand_field(1)
+        res = np.zeros(4, dtype=np.uint64)
+        ch = rand_field(logn)
+        chi = ctx.batch_inversion(C, ch)
+        runs = {
+            "fold_scalars": (96, lambda: ctx._chk(lib.bp_fold_scalars_dev(ctx.h, C, a.data_ptr(), b.data_ptr(), n, x.ctypes.data,
+                                                                          y.ctypes.data, o.data_ptr()))),
+            "inner_product": (64, lambda: ctx._chk(lib.bp_inner_product_dev(ctx.h, C, a.data_ptr(), b.data_ptr(), n, res.ctypes.data))),
+            "s_vector": (32, lambda: ctx._chk(lib.bp_s_vector_dev(ctx.h, C, ch.ctypes.data, chi.ctypes.data, logn, o.data_ptr()))),
+        }
+        for name, (bytes_per, fn) in runs.items():
+            ms = best(fn)
+            gbps = bytes_per * n / ms / 1e6
+            out[f"{name}_2_{logn}"] = {"ms": ms, "algorithmic_bytes": bytes_per * n, "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS,
+                                       "traffic": PMC_STREAM_2_24[name] if logn == 24 else None}
+        del a, b, o
+    torch.cuda.empty_cache()
     return out
 
 
 def cpu_baseline(n_sample):
     """C oracle (oracle/bp_oracle.c, a port of the bucket method) on all host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import c_oracle
-
-    co = c_oracle.COracle()
-    # the GPU box exposes the whole machine's CPUs; its share is OMP_NUM_THREADS (16 there)
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    cores = max(1, min(cores, co.max_threads()))
+    co, cores = _oracle_and_cores()
     rng = np.random.default_rng(SEED)
     ks = rng.integers(0, 1 << 64, (n_sample, 4), dtype=np.uint64)
     ks[:, 3] &= np.uint64((1 << 63) - 1)
@@ -203,12 +324,7 @@ def cpu_baseline(n_sample):
 def cpu_range_baseline(gs, hs, ugh, values, gamma, n_bits, seed, samples):
     """C oracle's range prover and verifier (oracle/bp_oracle_proto.c) on the host cores: the CPU
     figure beside the range-proof half of the metric.  A C restatement, not the arkworks binary."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import c_oracle
-
-    co = c_oracle.COracle()
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    cores = max(1, min(cores, co.max_threads()))
+    co, cores = _oracle_and_cores()
     tp, tv = [], []
     for _ in range(samples):
         t0 = time.perf_counter()
@@ -263,6 +379,20 @@ def range_proofs(ctx, device, workers=8, per_worker=8, cpu=True):
         "single_value_64_bit": {"workload": "one 64-bit value (benches/range_bench.rs:37-62 shape), one at a time, 1 GPU",
                                 "prove_ms": single["prove_ms"], "verify_ms": single["verify_ms"]},
     }
+    # verify_batch at BATCH_SIZE 100 (benches/aggregate_range_bench.rs:65-84): four distinct proofs cycled through a
+    # batch of 100, every proof's CRS scalars built and added on the device, one MSM (RangeAggregate::verify_batch)
+    rng = np.random.default_rng(seed + 9)
+    bvals = rng.integers(0, 1 << 64, (4, 64), dtype=np.uint64)
+    bgam = rng.integers(0, 1 << 64, (4, 64, 4), dtype=np.uint64)
+    bgam[:, :, 3] &= np.uint64((1 << 63) - 1)
+    host_mirror.range_aggregate_verify_batch(ctx, bp.SECP256K1, gs, hs, ugh, bvals, bgam, 64, 100, seed, seed + 1)  # warm-up
+    vb = host_mirror.range_aggregate_verify_batch(ctx, bp.SECP256K1, gs, hs, ugh, bvals, bgam, 64, 100, seed, seed + 1)
+    if not (vb["ok_direct"] and vb["ok_device"] and vb["ok_host"]):
+        raise SystemExit("verify_batch of 100 aggregated range proofs rejected valid proofs")
+    out["verify_batch_100"] = {"workload": "verify_batch, 100 proofs of 64 x 64 bits (benches/aggregate_range_bench.rs:65-84)",
+                               "ms": vb["direct_ms"], "proofs_per_s": 100.0 / vb["direct_ms"] * 1e3,
+                               "host_collect_then_device_merge_ms": vb["collect_ms"] + vb["device_merge_ms"],
+                               "host_collect_then_host_merge_ms": vb["collect_ms"] + vb["host_merge_ms"]}
     if cpu:
         out["cpu_baseline"] = cpu_range_baseline(gs, hs, ugh, values, gamma, 64, seed, 3)
         out["single_value_64_bit"]["cpu_baseline"] = cpu_range_baseline(g1, h1, ugh, values[:1], gamma[:1], 64, seed, 5)
@@ -310,6 +440,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-range", action="store_true", help="skip the aggregated range proof figures")
     ap.add_argument("--no-in-flight", action="store_true", help="skip the two-MSMs-in-flight figure")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the fold / dot / s-vector bandwidth figures")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 2^log2n points on every GPU; strong: 2^log2n points in total, split by shard_range")
     args = ap.parse_args()
@@ -435,7 +566,8 @@ def main():
                         "share of the multiplier's issue slots really used; frac_whole_step prices the whole MSM "
                         "(all launches and the host's part, ms_per_step) at the bucket method's count per point",
                 "traffic": (PMC_TRAFFIC_2_20["fetch_bytes"] + PMC_TRAFFIC_2_20["write_bytes"]) if args.log2n == LOG2_N and args.scaling == "weak" else None,
-                "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc runs; see profiles/)",
+                "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc runs of this command, taken from "
+                                "profiles/r02_v5_pmc_summary.csv: a constant from profiles/, not counted in this run)",
                 "algorithmic_bytes": float(n) * nw * (64 + 4),
             },
         }
@@ -445,8 +577,10 @@ def main():
             out["range_proofs"] = range_proofs(ctx, local_rank, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_in_flight:
             out["msm_two_in_flight"] = msm_in_flight(bp, local_rank, dx, dy, dk, n, args.steps)
+        if world == 1 and not args.no_streaming:
+            out["streaming"] = streaming_kernels(ctx, torch)
         if world == 1 and not args.no_range:
-            out["other_configs"] = other_configs(ctx, px, py)
+            out["other_configs"] = other_configs(ctx, px, py, cpu=not args.no_cpu_baseline)
         assert res is not None
         print(json.dumps(out), flush=True)
     if use_dist:

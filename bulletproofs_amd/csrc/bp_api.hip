@@ -116,15 +116,24 @@ struct bp_ctx {
   // vector polynomials left on the device by bp_range_agg_poly for bp_range_agg_eval (S_RANGE)
   size_t range_n = 0;
   int range_curve = -1;
-  // this device's copy of the file-scope scratch array of bp_inner_product_dev_noalloc (set by bp_init)
+  // this context's slice of its device's copy of the file-scope array of bp_inner_product_dev_noalloc
+  // (bp_init; null when the address could not be taken or every slice of the device is in use)
   u32* static_scratch = nullptr;
+  int noalloc_slot = -1;
 };
 
 // Scratch of bp_inner_product_dev_noalloc: the per-block partial sums (kDotBlocks field elements,
-// 32 KiB).  Every GPU the library runs on holds its own copy at its own address until the process
-// ends; host code reaches it only through the pointer bp_init obtains with hipGetSymbolAddress
-// while that GPU is current (the name itself is a host-side stand-in, not a device address).
-static __device__ __align__(256) u32 scratch[(size_t)kDotBlocks * 8];
+// 32 KiB) of up to kNoallocSlots contexts per GPU, one slice each (1 MiB in all).  Every GPU the
+// library runs on holds its own copy at its own address until the process ends; host code reaches
+// it only through the pointer bp_init obtains with hipGetSymbolAddress while that GPU is current
+// (the name itself is a host-side stand-in, not a device address).  A context owns its slice from
+// bp_init to bp_shutdown, so calls on different contexts of one GPU never share partial sums;
+// calls on one context are ordered by its lock and its stream.
+constexpr int kNoallocSlots = 32;
+constexpr int kNoallocMaxDevices = 64;
+static __device__ __align__(256) u32 g_noalloc_dot_partials[(size_t)kNoallocSlots * kDotBlocks * 8];
+static std::mutex g_noalloc_mu;
+static uint32_t g_noalloc_used[kNoallocMaxDevices];  // per device: bit s set = slice s is owned by a context
 
 struct bp_bases {
   bp_ctx* ctx;
@@ -475,14 +484,23 @@ int bp_init(int device, bp_ctx** out) {
     bp_shutdown(c);
     return BP_E_HIP;
   }
-  // address of this device's copy of the static scratch array (the device is current: hipSetDevice above)
-  {
+  // address of this device's copy of the static array (the device is current: hipSetDevice above) and
+  // a free slice of it.  Neither failing makes the library unusable: only the no-allocation entry
+  // point then reports BP_E_STATE on this context.
+  if (device < kNoallocMaxDevices) {
     void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
-      bp_shutdown(c);
-      return BP_E_HIP;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_dot_partials)) == hipSuccess && p) {
+      std::lock_guard<std::mutex> lk(g_noalloc_mu);
+      for (int s = 0; s < kNoallocSlots; s++)
+        if (!(g_noalloc_used[device] >> s & 1u)) {
+          g_noalloc_used[device] |= 1u << s;
+          c->noalloc_slot = s;
+          c->static_scratch = (u32*)p + (size_t)s * kDotBlocks * 8;
+          break;
+        }
+    } else {
+      (void)hipGetLastError();  // the failure is this entry point's alone
     }
-    c->static_scratch = (u32*)p;
   }
   *out = c;
   return BP_OK;
@@ -514,6 +532,10 @@ void bp_shutdown(bp_ctx* ctx) {
     if (p.reduce) (void)hipStreamDestroy(p.reduce);
   }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->noalloc_slot >= 0) {
+    std::lock_guard<std::mutex> lk(g_noalloc_mu);
+    g_noalloc_used[ctx->device] &= ~(1u << ctx->noalloc_slot);
+  }
   delete ctx;
 }
 
@@ -958,7 +980,8 @@ int bp_inner_product_dev_noalloc(bp_ctx* ctx, int curve, const uint64_t* d_a, co
   if (!curve_ok(curve)) return fail(ctx, BP_E_CURVE, "unsupported curve");
   if (n > BP_NOALLOC_MAX_N) return fail(ctx, BP_E_ARG, "bp_inner_product_dev_noalloc: n exceeds BP_NOALLOC_MAX_N (2^28)");
   Guard g(ctx);
-  if (!ctx->static_scratch) return fail(ctx, BP_E_STATE, "bp_inner_product_dev_noalloc: scratch address unknown");
+  if (!ctx->static_scratch)
+    return fail(ctx, BP_E_STATE, "bp_inner_product_dev_noalloc: this context has no slice of the static array (more than 32 contexts on the GPU?)");
   if (n == 0) {
     HIPCHK(ctx, hipMemsetAsync(d_out, 0, 32, ctx->stream));
     return BP_OK;

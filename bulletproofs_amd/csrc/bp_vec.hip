@@ -138,9 +138,10 @@ hipError_t launch_inner_product(int curve, const u32* a, const u32* b, size_t n,
 }
 
 // ---- lane-wise ops (src/vector_ops.rs:5-125) --------------------------------
+// out may be a or b (the accumulators of the batch verifier are updated in place): lane i reads
+// element i of both inputs before it writes element i, and no pointer is declared restrict.
 template <class F, int OP>
-__global__ __launch_bounds__(256) void k_vec_op(const u32* __restrict__ a, const u32* __restrict__ b,
-                                                FeArg sa, size_t n, u32* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_vec_op(const u32* a, const u32* b, FeArg sa, size_t n, u32* out) {
   const Fe s = arg_to_fe(sa);
   size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {

@@ -527,6 +527,15 @@ struct Ipa {
           "bp_ipa_verify_msm");
     return out;
   }
+  // ipa::verify (src/ipa/mod.rs:196-212) over the registered CRS; a proof of the wrong shape is rejected
+  static bool verify_resident(bp_ctx* ctx, const bp_bases* bases, size_t g_off, size_t h_off, size_t u_index,
+                              const Projective& p, size_t n, const IpaProof& proof, Transcript& t) {
+    try {
+      return is_zero(verify_value_resident(ctx, bases, g_off, h_off, u_index, p, n, proof, t));
+    } catch (const VerificationError&) {
+      return false;
+    }
+  }
 
   // verify_batch_aux (src/msm.rs:91-115) over inner-product arguments of one registered CRS with the CRS
   // part of every accumulator built and added on the device (bp_batch_axpy_ipa); P, L_j, R_j are scaled
@@ -546,7 +555,13 @@ struct Ipa {
     Scalar pw = S::one(), dummy = S::one(), minus_one = S::neg(S::one());
     for (const BatchItem& it : items) {
       const IpaProof& proof = *it.proof;
-      const size_t k = checked_rounds(proof.L.size(), proof.R.size(), n);
+      // a proof of the wrong shape rejects the batch (it has no accumulator to contribute)
+      size_t k;
+      try {
+        k = checked_rounds(proof.L.size(), proof.R.size(), n);
+      } catch (const VerificationError&) {
+        return false;
+      }
       std::vector<Scalar> xs(k), xinv(k);
       for (size_t j = 0; j < k; j++) {
         Projective lr[2] = {proof.L[j], proof.R[j]};

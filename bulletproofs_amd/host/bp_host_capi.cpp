@@ -5,6 +5,11 @@
 using namespace bp;
 using namespace bp::host;
 
+// A proof of the wrong shape that reached a driver which returns group elements rather than a verdict
+// (the verifiers that answer yes or no report it as a rejection, ok = 0 with BP_OK): distinct from the
+// device and argument errors of include/bp_gpu.h.
+#define BPH_E_VERIFY (-16)
+
 namespace {
 
 // Transcript stand-in: challenge number j of a run is SplitMix64(seed + j), four
@@ -120,6 +125,19 @@ int ipa_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uin
       SeededTranscript<Fr> tw(seed + 1000 * pi);
       try { I::verify_aux(ctx, crs, p, n, proof, tw); } catch (const VerificationError&) { refused++; }
       if (refused != 2) throw std::runtime_error("malformed proof not refused");
+      // ... and is a plain rejection for the verifiers that answer yes or no, alone or in a batch
+      SeededTranscript<Fr> ty(seed + 1000 * pi);
+      if (I::verify_resident(ctx, gh, 0, n, 2 * n, p, n, proof, ty)) throw std::runtime_error("malformed proof accepted");
+      batch_p.push_back(p);
+      batch_proofs.push_back(proof);
+      std::vector<SeededTranscript<Fr>> ts;
+      ts.reserve(batch_p.size());
+      std::vector<typename I::BatchItem> items(batch_p.size());
+      for (size_t q = 0; q < batch_p.size(); q++) ts.emplace_back(seed + 1000 * q);
+      for (size_t q = 0; q < batch_p.size(); q++) items[q] = typename I::BatchItem{&batch_p[q], &batch_proofs[q], &ts[q]};
+      SeededTranscript<Fr> tb(seed ^ 0xA1FAull);
+      if (I::verify_batch_resident(ctx, gh, 2 * n + 1, 0, n, 2 * n, n, items, tb.verifier_scalar()))
+        throw std::runtime_error("batch with a malformed proof accepted");
       *single_ok = 0;
       *batch_ok = 0;
       return 0;
@@ -168,6 +186,10 @@ int bph_msm_accumulate(bp_ctx* ctx, int curve, const uint64_t* x, const uint64_t
     if (curve == BP_SECP256K1) return msm_accumulate<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(ctx, x, y, inf, s, n, out_xyz, distinct);
     if (curve == BP_VESTA) return msm_accumulate<VestaFq, VestaFr, BP_VESTA>(ctx, x, y, inf, s, n, out_xyz, distinct);
     return BP_E_CURVE;
+  } catch (const VerificationError&) {
+    return BPH_E_VERIFY;
+  } catch (const std::invalid_argument&) {
+    return BP_E_ARG;
   } catch (const std::exception&) {
     return BP_E_HIP;
   }
@@ -188,6 +210,10 @@ int bph_ipa_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_t
       return ipa_roundtrip<VestaFq, VestaFr, BP_VESTA>(ctx, gx, gy, hx, hy, u_xy, a, b, n, n_proofs, seed, tamper, out_l,
                                                       out_r, out_ab, out_p, single_ok, batch_ok);
     return BP_E_CURVE;
+  } catch (const VerificationError&) {
+    return BPH_E_VERIFY;
+  } catch (const std::invalid_argument&) {
+    return BP_E_ARG;
   } catch (const std::exception&) {
     return BP_E_HIP;
   }
@@ -280,6 +306,19 @@ int range_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const u
         SeededTranscript<Fr> t3(seed_chal);
         try { R::verify_aux_stepwise(ctx, crs, vcom, n_bits, check_proof, t3, vrng); } catch (const VerificationError&) { refused++; }
         if (refused != 2) throw std::runtime_error("malformed proof not refused");
+        // ... and is a plain rejection for the verifiers that answer yes or no, alone or in a batch
+        SeededTranscript<Fr> t5(seed_chal);
+        SeededRandom<Fr> vrng5(seed_rand ^ 0x5EEDull);
+        const bool accepted = single ? R1::verify(ctx, crs, vcom[0], n_bits, check_proof, t5, vrng5)
+                                     : R::verify(ctx, crs, vcom, n_bits, check_proof, t5, vrng5);
+        if (accepted) throw std::runtime_error("malformed proof accepted");
+        {
+          SeededTranscript<Fr> tg(seed_chal), tbad(seed_chal), ta(seed_chal ^ 0xA1FAull);
+          SeededRandom<Fr> rg(seed_rand ^ 0x5EEDull), rbad(seed_rand ^ 0x5EEDull);
+          std::vector<typename R::BatchItem> items{{&vcom, &proof, &tg, &rg}, {&vcom, &check_proof, &tbad, &rbad}};
+          if (R::verify_batch(ctx, crs, n_bits, items, ta.verifier_scalar()))
+            throw std::runtime_error("batch with a malformed proof accepted");
+        }
         *ok = 0;
         continue;
       }
@@ -518,6 +557,10 @@ int bph_range_agg_throughput(int device, int curve, const uint64_t* gx, const ui
       return range_throughput<VestaFq, VestaFr, BP_VESTA>(device, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits, seed_rand,
                                                          seed_chal, workers, reps, prove_wall_ms, verify_wall_ms, ok);
     return BP_E_CURVE;
+  } catch (const VerificationError&) {
+    return BPH_E_VERIFY;
+  } catch (const std::invalid_argument&) {
+    return BP_E_ARG;
   } catch (const std::exception&) {
     return BP_E_HIP;
   }
@@ -540,6 +583,10 @@ int bph_range_agg_verify_batch(bp_ctx* ctx, int curve, const uint64_t* gx, const
                                                            seed_chal, distinct, batch, tamper, collect_ms, device_merge_ms,
                                                            host_merge_ms, ok_device, ok_host, direct_ms, ok_direct);
     return BP_E_CURVE;
+  } catch (const VerificationError&) {
+    return BPH_E_VERIFY;
+  } catch (const std::invalid_argument&) {
+    return BP_E_ARG;
   } catch (const std::exception&) {
     return BP_E_HIP;
   }
@@ -568,6 +615,10 @@ int bph_range_agg_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const ui
                                                         seed_chal, tamper, reps, single, out_points, out_scalars, out_lr,
                                                         out_value, prove_ms, verify_ms, ok);
     return BP_E_CURVE;
+  } catch (const VerificationError&) {
+    return BPH_E_VERIFY;
+  } catch (const std::invalid_argument&) {
+    return BP_E_ARG;
   } catch (const std::exception&) {
     return BP_E_HIP;
   }
@@ -708,6 +759,10 @@ int bph_poly_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_
                                                        tamper, halo, out_l, out_r, out_ar, out_g, out_commit, out_eval,
                                                        prove_ms, verify_ms, ok_verify, ok_lazy, ok_halo, halo_out, halo_w);
     return BP_E_CURVE;
+  } catch (const VerificationError&) {
+    return BPH_E_VERIFY;
+  } catch (const std::invalid_argument&) {
+    return BP_E_ARG;
   } catch (const std::exception&) {
     return BP_E_HIP;
   }

@@ -296,9 +296,15 @@ struct RangeAggregate {
           "bp_range_agg_verify_msm");
     return out;
   }
+  // A proof of the wrong shape is a rejection, as the reference's Err(VerificationError) is to its callers
+  // (src/range/aggregate.rs:284-299), not a failure of the call.
   static bool verify(bp_ctx* ctx, const Crs& crs, const std::vector<Projective>& v_commit, unsigned n_bits,
                      const RangeProof& pr, Transcript& t, RandomSource& rng) {
-    return is_zero(verify_value(ctx, crs, v_commit, n_bits, pr, t, rng));
+    try {
+      return is_zero(verify_value(ctx, crs, v_commit, n_bits, pr, t, rng));
+    } catch (const VerificationError&) {
+      return false;
+    }
   }
 
   // verify_batch_aux (src/msm.rs:91-115) over aggregated range proofs of one CRS with nothing but the
@@ -321,7 +327,14 @@ struct RangeAggregate {
     M rest(ctx);
     Scalar pw = S::one(), dummy = S::one();
     for (const BatchItem& it : items) {
-      const VerifyPlan vp = verify_plan(crs, *it.v_commit, n_bits, *it.proof, *it.transcript, *it.rng);
+      // one malformed proof rejects the batch (verify_batch_aux takes the proofs' accumulators, and
+      // verify_aux has none to give for it: src/msm.rs:91-115)
+      VerifyPlan vp;
+      try {
+        vp = verify_plan(crs, *it.v_commit, n_bits, *it.proof, *it.transcript, *it.rng);
+      } catch (const VerificationError&) {
+        return false;
+      }
       const size_t k = vp.k;
       check(ctx, bp_batch_axpy_range_agg(batch, pw.l, k ? vp.xs[0].l : dummy.l, k ? vp.xinv[0].l : dummy.l, k,
                                          it.proof->ipa.a.l, it.proof->ipa.b.l, vp.y_inv.l, vp.z.l, vp.m, n_bits,
@@ -462,7 +475,11 @@ struct Range {
   }
   static bool verify(bp_ctx* ctx, const Crs& crs, const Projective& v_commit, unsigned n_bits, const RangeProof& pr,
                      Transcript& t, RandomSource& rng) {
-    return is_zero(verify_value(ctx, crs, v_commit, n_bits, pr, t, rng));
+    try {
+      return is_zero(verify_value(ctx, crs, v_commit, n_bits, pr, t, rng));
+    } catch (const VerificationError&) {
+      return false;
+    }
   }
 };
 

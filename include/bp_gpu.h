@@ -346,13 +346,16 @@ int bp_inner_product_dev(bp_ctx* ctx, int curve, const uint64_t* d_a, const uint
                          size_t n, uint64_t out[4]);
 /* bp_inner_product_dev for callers that cannot allocate (code under HIP graph capture, serving
  * loops and harnesses that forbid hipMalloc): no counterpart in the reference.  Same kernels and
- * same value as bp_inner_product_dev, but the block partial sums live in a 32 KiB static device
- * array instead of the context's workspace, the result (4 u64) is written to the device pointer
- * d_out, and the call only enqueues on the context's stream: it calls no hipMalloc, hipFree,
+ * same value as bp_inner_product_dev, but the block partial sums live in a static device array
+ * instead of the context's workspace, the result (4 u64) is written to the device pointer d_out,
+ * and the call only enqueues on the context's stream: it calls no hipMalloc, hipFree,
  * pinned-memory or other allocating routine and does not synchronise (bp_sync, or stream order,
  * before reading d_out).  n <= BP_NOALLOC_MAX_N, larger sizes are refused with BP_E_ARG.  Each GPU
- * holds one copy of the array for the life of the process and all contexts on that GPU share it:
- * calls that overlap on one GPU (different contexts or streams) race on it; serialise them. */
+ * holds one copy of the array (1 MiB: 32 slices of 32 KiB) for the life of the process; a context
+ * owns one slice from bp_init to bp_shutdown, so calls on different contexts of a GPU do not
+ * interfere, and calls on one context are ordered by its lock and stream.  The 33rd context alive
+ * on one GPU gets no slice: this entry point then returns BP_E_STATE on it (every other entry point
+ * works).  The slice keeps the last call's partial sums; every call overwrites the ones it reads. */
 #define BP_NOALLOC_MAX_N ((size_t)1 << 28)
 int bp_inner_product_dev_noalloc(bp_ctx* ctx, int curve, const uint64_t* d_a, const uint64_t* d_b,
                                  size_t n, uint64_t* d_out);

@@ -272,3 +272,34 @@ def test_config5_poly_commit_2_20_with_halo_fold(ctx, coracle):
     (src/poly_commit/mod.rs:121-173), whose n-point MSM also pins their folded generators; the
     folded witness and statement equal the oracle's"""
     check_poly(ctx, coracle, o.SECP256K1, 20, 1 << 20, reprove_all=False)
+
+
+def test_config4_verify_batch_of_100_at_full_size(ctx, coracle):
+    """verify_batch at BATCH_SIZE 100 over 64 x 64-bit aggregated range proofs
+    (benches/aggregate_range_bench.rs:65-84, src/msm.rs:91-115): four distinct proofs cycled through the
+    batch; the device-side combination, the combination of host accumulators on the device and the
+    reference's host merge all accept; every distinct proof is the one the single-proof driver
+    produces from the same seeds and is accepted by the oracle's verifier; with the last proof of
+    the batch corrupted all three reject"""
+    from bulletproofs_amd import host_mirror
+
+    c = o.SECP256K1
+    m, n_bits, distinct, batch = 64, 64, 4, 100
+    n = m * n_bits
+    rng = o.SplitMix64(SEED + 44)
+    threads = coracle.max_threads()
+    G, H = gen_points(coracle, c, rng, n), gen_points(coracle, c, rng, n)
+    ugh = np.stack([xy8(o.scalar_mul(rng.field(c.n), c.g, c), c) for _ in range(3)])
+    values = np.random.default_rng(SEED + 45).integers(0, 1 << 63, (distinct, m), dtype=np.uint64)
+    gamma = rand_scalars(SEED + 46, distinct * m).reshape(distinct, m, 4)
+    res = host_mirror.range_aggregate_verify_batch(ctx, c.id, G, H, ugh, values, gamma, n_bits, batch, seed_rand=51, seed_chal=52)
+    assert res["ok_direct"] and res["ok_device"] and res["ok_host"]
+    for p in range(distinct):
+        one = host_mirror.range_aggregate_roundtrip(ctx, c.id, G, H, ugh, values[p], gamma[p], n_bits, seed_rand=51 + p, seed_chal=52 + p)
+        assert one["ok"]
+        ov = coracle.range_agg_verify(c.id, G, H, ugh, values[p], gamma[p], n_bits, one["points"], one["scalars"], one["lr"],
+                                      (51 + p) ^ 0x5EED, 52 + p, threads=threads)
+        assert is_identity(ov), p
+    bad = host_mirror.range_aggregate_verify_batch(ctx, c.id, G, H, ugh, values, gamma, n_bits, batch, seed_rand=51, seed_chal=52,
+                                                   tamper=True)
+    assert not bad["ok_direct"] and not bad["ok_device"] and not bad["ok_host"]

@@ -66,13 +66,20 @@ __global__ __launch_bounds__(1024) void k_rate(int iters, u64* cycles, u32* sink
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// iterations per launch (argv[1]; 2000 = launches of 0.3-2 ms, 200000 = launches of 30-200 ms, long enough
+// for the clock the GPU holds under sustained load) and whether only the multiply tests run (argv[2])
+static int g_iters = 2000;
+static bool g_quick = false;
+
 template <int ID>
 void run(const char* name, int per_iter_instrs) {
+  if (g_quick && ID != 0 && ID != 1 && ID != 11 && ID != 2) return;
   u64* d_cyc; u32* d_sink;
   hipMalloc(&d_cyc, 4096 * 8); hipMalloc(&d_sink, 64);
-  const int iters = 2000;
-  for (int waves = 1; waves <= 4; waves *= 2) {
-    int threads = 256 * waves, blocks = 256;  // one block per CU, `waves` waves on each SIMD
+  const int iters = g_iters;
+  for (int waves = 1; waves <= 8; waves *= 2) {
+    // one block per CU with `waves` waves on each SIMD; eight waves per SIMD as two blocks per CU
+    int threads = 256 * (waves > 4 ? 4 : waves), blocks = 256 * (waves > 4 ? waves / 4 : 1);
     hipLaunchKernelGGL(k_rate<ID>, dim3(blocks), dim3(threads), 0, 0, 10, d_cyc, d_sink);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -80,16 +87,20 @@ void run(const char* name, int per_iter_instrs) {
     hipLaunchKernelGGL(k_rate<ID>, dim3(blocks), dim3(threads), 0, 0, iters, d_cyc, d_sink);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    u64 h[256]; hipMemcpy(h, d_cyc, 256 * 8, hipMemcpyDeviceToHost);
+    u64 h[512]; hipMemcpy(h, d_cyc, 256 * 8, hipMemcpyDeviceToHost);
     double avg = 0; for (int i = 0; i < 256; i++) avg += (double)h[i]; avg /= 256;
     double n_instr = (double)iters * 64 * per_iter_instrs;  // wave-instructions per wave
     // cycles per wave-instruction per SIMD = block cycles / (instructions per wave * waves per SIMD)
     printf("%-34s waves/SIMD %d: %6.2f cyc/instr/SIMD (counter)  %7.3f ms  -> %.2f Ginstr/s/SIMD-lane-group\n", name, waves,
-           avg / (n_instr * waves), ms, n_instr * waves * 1024 / (ms * 1e-3) / 1e9);
+           avg / (n_instr * (waves > 4 ? 4 : waves)), ms, n_instr * waves * 1024 / (ms * 1e-3) / 1e9);
   }
+  hipFree(d_cyc); hipFree(d_sink);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) g_iters = atoi(argv[1]);
+  if (argc > 2) g_quick = atoi(argv[2]) != 0;
+  if (g_iters < 1) g_iters = 2000;
   run<0>("v_mad_u64_u32", 1);
   run<14>("v_mad_u64_u32 const", 1);
   run<15>("v_mad_u64_u32 sgpr carry", 1);
