@@ -59,7 +59,8 @@ def best(fn, reps=5):
     return min(ts), float(np.median(ts))
 
 
-peak = ctx.int_mad_peak(4000)
+ctx.int_mad_peak(12000)  # warm-up launch: the clock the GPU holds under load
+peak = max(ctx.int_mad_peak(12000) for _ in range(3))  # launches of >= 50 ms, as bench.py's probe
 print(json.dumps({"kernel": "v_mad_u64_u32 peak", "mac_per_s": peak}), flush=True)
 
 # ---- what this GPU's memory delivers to the simplest kernels (torch's own copy, fill and sum over
