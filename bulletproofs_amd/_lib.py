@@ -113,7 +113,6 @@ SIGNATURES = {
     "bp_ipa_round_fold": (ci, [vp, vp, vp]),
     "bp_ipa_len": (sz, [vp]),
     "bp_bases_precompute": (ci, [vp]),
-    "bp_bases_precompute_wide": (ci, [vp]),
     "bp_msm_resident_s_vector": (ci, [vp, vp, sz, vp, vp, sz, vp]),
     "bp_bases_register_compressed": (ci, [vp, ci, vp, sz, C.POINTER(vp)]),
     "bp_scalars_to_bytes": (ci, [vp, ci, vp, sz, vp]),

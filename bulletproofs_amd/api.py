@@ -410,12 +410,6 @@ class Bases:
         self.ctx._chk(lib.bp_bases_precompute(self.h))
         return self
 
-    def precompute_wide(self):
-        """wide window tables for this base set (bp_bases_precompute_wide): single sums over 2^16 .. 2^21
-        of its points then use one bucket set for all digit windows"""
-        self.ctx._chk(lib.bp_bases_precompute_wide(self.h))
-        return self
-
     def msm_s_vector(self, challenges, challenge_inverses, offset=0):
         """<s-vector of the challenges, bases[offset, offset + 2^k)> with the scalars built on the device
         (bp_msm_resident_s_vector; src/poly_commit/mod.rs:109-111,152-159)"""

@@ -143,7 +143,6 @@ struct bp_bases {
   u32* y;
   uint8_t* inf;
   u32* tab = nullptr;  // window tables (bp_bases_precompute): kTableWindows * n records of 64 bytes
-  u32* tab_wide = nullptr;  // wide window tables (bp_bases_precompute_wide): kWideWindows * n records of 64 bytes
 };
 
 // Accumulator of bp_batch_*: one scalar per point of a registered base set, on the device
@@ -345,9 +344,9 @@ void finish_windows(int curve, const uint64_t* win, int n_windows, int c, uint64
 // room for `host_extra` more bytes is kept behind them)
 int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, MsmPlan* plan,
                u32** d_windows, int groups = 1, const MsmExtra* extra = nullptr, const MsmTable* table = nullptr,
-               bool win_host = false, size_t host_extra = 0, size_t host_offset = 0) {
+               bool win_host = false, size_t host_extra = 0) {
   size_t n = p0.n + p1.n + (extra ? 2 : 0);
-  hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan, table ? table->stride : 0, true, table && table->wide);
+  hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan, table ? table->stride : 0, true);
   if (e != hipSuccess) return fail(ctx, BP_E_ARG, "msm plan (n too large?)", e);
   MsmWorkspace ws{};
   void* p;
@@ -375,8 +374,8 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
   CHK(reserve(ctx, S_SEGS, plan->seg_bytes, &p)); ws.segs = (u32*)p;
   CHK(reserve(ctx, S_SEG_GROUPS, plan->seg_group_bytes, &p)); ws.seg_groups = (u32*)p;
   if (win_host) {
-    CHK(reserve_pinned(ctx, host_offset + plan->win_bytes + host_extra));
-    ws.windows = (u32*)((char*)ctx->pinned + host_offset);
+    CHK(reserve_pinned(ctx, plan->win_bytes + host_extra));
+    ws.windows = (u32*)ctx->pinned;
   } else {
     CHK(reserve(ctx, S_WINDOWS, plan->win_bytes, &p)); ws.windows = (u32*)p;
   }
@@ -415,41 +414,6 @@ int msm_full(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, uint6
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   msm_collect_times(ctx, plan.n_total != 0);
   finish_windows(curve, (const uint64_t*)ctx->pinned, plan.n_windows, plan.finish_c, out_xyz);
-  return BP_OK;
-}
-
-// window sums of up to this many windows fit one slot of the pinned result buffer (two MSMs of one call
-// leave theirs side by side)
-constexpr size_t kWinSlotBytes = 64 * 128;
-
-const MsmTable* pick_table(const bp_bases* bases, size_t n, MsmTable* storage);
-void add_results(int curve, const uint64_t a[12], const uint64_t b[12], uint64_t out[12]);
-
-// sum over a range of a registered base set (p0, device scalars) plus a few other points (p1, may be
-// empty).  With wide tables for the range the two parts are two passes on the stream -- the other points
-// first, through the plain pipeline, then the range over its tables -- with one synchronisation, and the
-// host adds the two results; otherwise one pass over both parts.
-int msm_full_resident(bp_ctx* ctx, const bp_bases* bases, MsmPart p0, const MsmPart& p1, size_t offset,
-                      uint64_t out_xyz[12]) {
-  const int curve = bases->curve;
-  MsmTable table;
-  const MsmTable* t = pick_table(bases, p0.n, &table);
-  p0.tab_offset = offset;
-  MsmPart none{nullptr, nullptr, nullptr, nullptr, 0};
-  if (!t || !t->wide) return msm_full(ctx, curve, p0, p1, out_xyz, p1.n == 0 ? t : nullptr);
-  if (p1.n == 0) return msm_full(ctx, curve, p0, none, out_xyz, t);
-  CHK(reserve_pinned(ctx, 2 * kWinSlotBytes));
-  MsmPlan plan_e, plan_w;
-  u32* d_win = nullptr;
-  CHK(msm_device(ctx, curve, p1, none, &plan_e, &d_win, 1, nullptr, nullptr, true, 0, 0));
-  if (plan_e.win_bytes > kWinSlotBytes) return fail(ctx, BP_E_ARG, "msm_full_resident: too many windows");
-  CHK(msm_device(ctx, curve, p0, none, &plan_w, &d_win, 1, nullptr, t, true, 0, kWinSlotBytes));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  msm_collect_times(ctx, plan_w.n_total != 0);
-  uint64_t a[12], b[12];
-  finish_windows(curve, (const uint64_t*)ctx->pinned, plan_e.n_windows, plan_e.finish_c, a);
-  finish_windows(curve, (const uint64_t*)((const char*)ctx->pinned + kWinSlotBytes), plan_w.n_windows, plan_w.finish_c, b);
-  add_results(curve, a, b, out_xyz);
   return BP_OK;
 }
 
@@ -515,10 +479,6 @@ int bp_init(int device, bp_ctx** out) {
     bp_shutdown(c);
     return BP_E_HIP;
   }
-  if (hipHostMalloc(&c->pinned, 65536, hipHostMallocDefault) == hipSuccess)
-    c->pinned_cap = 65536;  // grows on demand; large enough for the window sums of any two passes
-  else
-    c->pinned = nullptr;
   if (hipHostMalloc((void**)&c->stage, kStageBytes, hipHostMallocDefault) != hipSuccess) {
     c->stage = nullptr;
     bp_shutdown(c);
@@ -749,7 +709,6 @@ void bp_bases_free(bp_bases* b) {
   (void)hipFree(b->y);
   (void)hipFree(b->inf);
   if (b->tab) (void)hipFree(b->tab);
-  if (b->tab_wide) (void)hipFree(b->tab_wide);
   delete b;
 }
 
@@ -771,57 +730,7 @@ int bp_bases_precompute(bp_bases* b) {
   return BP_OK;
 }
 
-int bp_bases_precompute_wide(bp_bases* b) {
-  if (!b) return BP_E_ARG;
-  bp_ctx* ctx = b->ctx;
-  Guard g(ctx);
-  if (b->tab_wide || b->n == 0) return BP_OK;
-  if (b->n > ((size_t)1 << 22)) return fail(ctx, BP_E_ARG, "bp_bases_precompute_wide: base set too large (more than 2^22 points)");
-  u32* tab = nullptr;
-  HIPCHK(ctx, hipMalloc((void**)&tab, (size_t)kWideWindows * b->n * 64));
-  hipError_t e = launch_window_tables(b->curve, b->x, b->y, b->inf, b->n, kWideWindowBits, kWideWindows, tab, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) {
-    (void)hipFree(tab);
-    return fail(ctx, BP_E_HIP, "bp_bases_precompute_wide", e);
-  }
-  b->tab_wide = tab;
-  return BP_OK;
-}
-
 size_t bp_bases_len(const bp_bases* b) { return b ? b->n : 0; }
-
-namespace {
-// the table a single sum over bases[offset, offset + n) reads its points from, if any: the narrow
-// tables up to kTableMaxPoints points, the wide ones from kWideMinPoints to kWideMaxPoints
-const MsmTable* pick_table(const bp_bases* bases, size_t n, MsmTable* storage) {
-  if (bases->tab_wide && n >= kWideMinPoints && n <= kWideMaxPoints && !getenv("BP_MSM_NO_WIDE")) {
-    *storage = MsmTable{bases->tab_wide, bases->n, true};
-    return storage;
-  }
-  if (bases->tab && n <= kTableMaxPoints) {
-    *storage = MsmTable{bases->tab, bases->n, false};
-    return storage;
-  }
-  return nullptr;
-}
-
-// a + b of two normalised results (X, Y, Z with Z = 1 or the identity), normalised
-void add_results(int curve, const uint64_t a[12], const uint64_t b[12], uint64_t out[12]) {
-  uint64_t win[32];
-  auto put = [&](const uint64_t* p, uint64_t* w) {  // XYZZ: x, y, zz = zzz = Z (1 or 0)
-    memcpy(w, p, 64);
-    memcpy(w + 8, p + 8, 32);
-    memcpy(w + 12, p + 8, 32);
-  };
-  put(a, win);
-  put(b, win + 16);
-  if (curve == BP_SECP256K1)
-    host::hj_combine_windows<host::MontOps<Secp256k1Fq>>(win, 2, 0, out);
-  else
-    host::hj_combine_windows<host::MontOps<VestaFq>>(win, 2, 0, out);
-}
-}  // namespace
 
 int bp_msm_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n, const uint64_t* scalars,
                     uint64_t out_xyz[12]) {
@@ -833,7 +742,9 @@ int bp_msm_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
   CHK(upload(ctx, S_IN3, scalars, n * 32, &ds));
   MsmPart p0{bases->x + offset * 8, bases->y + offset * 8, bases->inf + offset, (const u32*)ds, n};
   MsmPart p1{nullptr, nullptr, nullptr, nullptr, 0};
-  return msm_full_resident(ctx, bases, p0, p1, offset, out_xyz);
+  p0.tab_offset = offset;
+  MsmTable table{bases->tab, bases->n};
+  return msm_full(ctx, bases->curve, p0, p1, out_xyz, bases->tab && n <= kTableMaxPoints ? &table : nullptr);
 }
 
 int bp_msm_resident_pair(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n, const uint64_t* scalars_a,
@@ -885,7 +796,7 @@ int bp_msm_resident_plus(bp_ctx* ctx, const bp_bases* bases, size_t offset, size
   }
   MsmPart p0{bases->x + offset * 8, bases->y + offset * 8, bases->inf + offset, (const u32*)ds, n};
   MsmPart p1{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)des, n_extra};
-  return msm_full_resident(ctx, bases, p0, p1, offset, out_xyz);
+  return msm_full(ctx, bases->curve, p0, p1, out_xyz);
 }
 
 namespace {
@@ -1046,7 +957,7 @@ int bp_batch_msm(bp_batch* b, const uint64_t* extra_x, const uint64_t* extra_y, 
   }
   MsmPart p0{b->bases->x, b->bases->y, b->bases->inf, b->acc, b->n};
   MsmPart p1{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)des, n_extra};
-  return msm_full_resident(ctx, b->bases, p0, p1, 0, out_xyz);
+  return msm_full(ctx, b->bases->curve, p0, p1, out_xyz);
 }
 
 // ---- field-vector kernels ------------------------------------------------------
@@ -1240,7 +1151,7 @@ int bp_msm_resident_s_vector(bp_ctx* ctx, const bp_bases* bases, size_t offset, 
   CHK(s_vector_common(ctx, bases->curve, ch, ch_inv, k, (u32*)ds));
   MsmPart p0{bases->x + offset * 8, bases->y + offset * 8, bases->inf + offset, (const u32*)ds, n};
   MsmPart p1{nullptr, nullptr, nullptr, nullptr, 0};
-  return msm_full_resident(ctx, bases, p0, p1, offset, out_xyz);
+  return msm_full(ctx, bases->curve, p0, p1, out_xyz);
 }
 
 int bp_powers(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* out) {
@@ -1434,7 +1345,7 @@ int bp_range_agg_verify_msm(bp_ctx* ctx, const bp_bases* bases, const uint64_t* 
   }
   MsmPart p0{bases->x, bases->y, bases->inf, (const u32*)dsc, 2 * n + 1};
   MsmPart p1{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)des, n_extra};
-  return msm_full_resident(ctx, bases, p0, p1, 0, out_xyz);
+  return msm_full(ctx, curve, p0, p1, out_xyz);
 }
 
 int bp_batch_axpy_range_agg(bp_batch* b, const uint64_t weight[4], const uint64_t* challenges,
@@ -1550,7 +1461,7 @@ int bp_ipa_verify_msm(bp_ctx* ctx, const bp_bases* bases, size_t g_offset, size_
   }
   MsmPart p0{bases->x + lo * 8, bases->y + lo * 8, bases->inf + lo, (const u32*)dsc, hi - lo};
   MsmPart p1{(const u32*)dx, (const u32*)dy, (const uint8_t*)di, (const u32*)des, n_extra};
-  return msm_full_resident(ctx, bases, p0, p1, lo, out_xyz);
+  return msm_full(ctx, curve, p0, p1, out_xyz);
 }
 
 int bp_batch_inverse(bp_ctx* ctx, int curve, int field, uint64_t* v, size_t n) {

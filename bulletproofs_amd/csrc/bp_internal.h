@@ -149,18 +149,9 @@ struct MsmPart {
 struct MsmTable {
   const u32* rec = nullptr;
   size_t stride = 0;
-  // wide tables (kWideWindowBits-bit windows): single sums over many points whose digit windows all
-  // feed ONE bucket set (see MsmPlan::wide)
-  bool wide = false;
 };
 constexpr int kTableWindowBits = 8;
 constexpr int kTableWindows = 32;
-constexpr int kWideWindowBits = 16;
-constexpr int kWideWindows = 16;
-// single sums over wide tables: point counts the plan is used for (below, the narrow tables or the plain
-// pipeline are faster; above, a partition of the counting sort outgrows one block)
-constexpr size_t kWideMinPoints = (size_t)1 << 16;
-constexpr size_t kWideMaxPoints = (size_t)1 << 21;
 
 struct MsmPlan {
   int c;          // window bits
@@ -190,13 +181,6 @@ struct MsmPlan {
   int digit_windows;  // windows of the digit decomposition (= group_windows unless tab)
   int stages;     // > 1: the windows are processed in this many consecutive batches on three streams
   bool two_level; // chunked path: two-level counting sort in place of the key-value radix sort
-  // Single sum over wide window tables: record (w, j) = 2^(16w) * P_j, so digit w of scalar j adds that
-  // record to bucket |digit| of the ONE bucket set of the sum (32768 buckets holding 16n entries): the
-  // accumulation is that of the plain pipeline, the bucket reduction runs over one window instead of
-  // sixteen, nothing is packed, and the host has no doublings left.  lo_bits: bucket bits below the
-  // partition number of the counting sort; idx_bits: bits of a table record's index in a sort word.
-  bool wide;
-  int lo_bits, idx_bits;
   bool rowcol;    // bucket reduction by row and column sums of the (n_buckets/256) x 256 bucket matrix
 };
 
@@ -215,7 +199,7 @@ struct MsmPipe {
 int msm_choose_window(size_t n);
 int msm_default_window(size_t n);
 hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride = 0,
-                         bool allow_stages = false, bool wide_table = false);
+                         bool allow_stages = false);
 
 struct MsmWorkspace {
   u32* packed;        // points as x|y pairs, 16 u32 each

@@ -99,27 +99,25 @@ static int key_bits_for(u32 max_key) {
 }
 
 hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride,
-                         bool allow_stages, bool wide_table) {
+                         bool allow_stages) {
   MsmPlan p{};
   if (groups < 1 || groups > 2) return hipErrorInvalidValue;
   p.groups = groups;
   p.tab = table_stride != 0 && n_total > 0;
-  p.wide = p.tab && wide_table;
-  if (p.wide && (groups != 1 || n_total > kWideMaxPoints)) return hipErrorInvalidValue;
   p.c = (c_override >= 2 && c_override <= 20) ? c_override : msm_choose_window(n_total / groups);
   const bool small_ok = n_total > 0 && n_total <= kSmallMaxPoints && !getenv("BP_MSM_NO_SMALL");
   if (small_ok && !(c_override >= 2 && c_override <= 20)) p.c = n_total / groups >= 512 ? 8 : 4;
-  if (p.tab) p.c = p.wide ? kWideWindowBits : kTableWindowBits;
+  if (p.tab) p.c = kTableWindowBits;
   // k_digits maps a scalar k > r/2 to r - k (and negates the point), so digits
   // come from a value below 2^255 (secp256k1) or 2^254 (Vesta); one more bit
   // absorbs the carry of the signed recoding.
   const int value_bits = curve == BP_VESTA ? 254 : 255;
   p.group_windows = (value_bits + 1 + p.c - 1) / p.c;
   p.digit_windows = p.group_windows;
-  p.tab_virtual = p.tab && !p.wide && small_ok && p.digit_windows * groups <= 64 && !getenv("BP_MSM_TAB_MERGED");
-  p.finish_c = p.tab_virtual || p.wide ? 0 : p.c;
+  p.tab_virtual = p.tab && small_ok && p.digit_windows * groups <= 64 && !getenv("BP_MSM_TAB_MERGED");
+  p.finish_c = p.tab_virtual ? 0 : p.c;
   if (p.tab) {
-    if (p.digit_windows > (p.wide ? kWideWindows : kTableWindows)) return hipErrorInvalidValue;
+    if (p.digit_windows > kTableWindows) return hipErrorInvalidValue;
     // every digit window lands in the one bucket set of its group: one output "window" per group
     // (unless the plan keeps them apart, see tab_virtual)
     if (!p.tab_virtual) p.group_windows = 1;
@@ -179,18 +177,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   while ((1 << wbits) < p.n_windows) wbits++;
   p.wshift = 31 - wbits;
   if (n_total >= ((size_t)1 << p.wshift)) return hipErrorInvalidValue;
-  if (p.tab && !p.wide && (size_t)kTableWindows * table_stride >= ((size_t)1 << p.wshift)) return hipErrorInvalidValue;
-  if (p.wide) {
-    // sort word of the wide plan: record index | low bucket bits | sign.  About 8192 entries per
-    // partition of the counting sort (one block sorts a partition; it keeps up to 15 * 1024 entries),
-    // between 8 and 4096 partitions
-    p.idx_bits = 1;
-    while (((size_t)1 << p.idx_bits) < (size_t)kWideWindows * table_stride) p.idx_bits++;
-    p.lo_bits = 8;
-    while (p.lo_bits > 3 && (p.entries >> (p.c - 1 - p.lo_bits)) > 8192) p.lo_bits--;
-    if (p.idx_bits + p.lo_bits > 31) p.lo_bits = 31 - p.idx_bits;
-    if (p.lo_bits < 3 || (p.entries >> (p.c - 1 - p.lo_bits)) > 14000) return hipErrorInvalidValue;
-  }
+  if (p.tab && (size_t)kTableWindows * table_stride >= ((size_t)1 << p.wshift)) return hipErrorInvalidValue;
   p.sort_tmp_bytes = 256;
   // chunk length: up to 24 entries, shorter when the problem is small so that there are still
   // tens of thousands of lanes (2^20 points, 16-bit windows, per step: 1.485 ms at 16, 1.450 at 24,
@@ -215,8 +202,8 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   p.nc_cap = p.entries / p.chunk + nbt + 1 + kMsmMaxStages;  // room for one rounding slot per batch
   p.small = small_ok && p.n_buckets <= kSmallMaxBuckets && (!p.tab || p.tab_virtual);
   // narrow windows on more points than one block sorts: the sliced counting sort
-  p.mid = !p.wide && ((p.tab && !p.tab_virtual) || (!p.small && n_total > 0 && p.n_buckets >= 64 && p.n_buckets <= kMidMaxBuckets &&
-                    n_total <= ((size_t)1 << 20) && !getenv("BP_MSM_NO_MID")));
+  p.mid = (p.tab && !p.tab_virtual) || (!p.small && n_total > 0 && p.n_buckets >= 64 && p.n_buckets <= kMidMaxBuckets &&
+                    n_total <= ((size_t)1 << 20) && !getenv("BP_MSM_NO_MID"));
   if (p.small || p.mid) {
     // every output window owns a fixed range of slots of the sorted-entry array: n_total, or
     // all of a group's digit windows together for table plans
@@ -237,16 +224,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
                 (size_t)groups * (p.n_buckets >> kTwoLevelLoBits) <= (1u << kTwoLevelLoBits) &&
                 (size_t)p.n_windows * (p.n_buckets >> kTwoLevelLoBits) <= kTwoLevelMaxBins &&
                 nbt + 2 >= 2 * (size_t)kTwoLevelMaxBins && !getenv("BP_MSM_RADIX");
-  if (p.wide) {
-    // every bucket holds hundreds of entries, all chunks are full: longer chunks leave fewer partial
-    // sums to join (16 n / 32768 entries per bucket)
-    p.chunk = 32;
-    if (getenv("BP_MSM_WIDE_CHUNK")) p.chunk = (u32)atoi(getenv("BP_MSM_WIDE_CHUNK"));  // tuning runs
-    if (p.chunk < 4) p.chunk = 4;
-    p.nc_cap = p.entries / p.chunk + nbt + 1 + kMsmMaxStages;
-    p.packed_bytes = 256;  // the table records are read where they lie
-  }
-  if (!p.small && !p.mid && !p.two_level && !p.wide) {
+  if (!p.small && !p.mid && !p.two_level) {
     // only the plans that still sort with the library's radix sort (more than 2^22 points, window
     // widths without a high bucket part, BP_MSM_RADIX) ask it for its temporary storage
     hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, const u32*, u32*, const u32*, u32*>(
@@ -1062,235 +1040,6 @@ __global__ __launch_bounds__(1024) void k_two_sort_lo(const u32* __restrict__ wo
       const u32 word = valid ? words[s + p] : 0u;
       const u32 pos = lds_rank(off, (word >> kTwoIdxBits) & (kTwoLo - 1), valid);
       if (valid) sorted_vals[s + pos] = (word & idx_mask) | wbits | (word & 0x80000000u);
-    }
-  }
-}
-
-// ---- 1-3 for single sums over wide window tables -------------------------------------------
-// All digit windows feed one bucket set (MsmPlan::wide), so the counting sort runs over the bucket
-// number alone: partition = its high bits (n_hi of them), lo_bits low bits are sorted inside a
-// partition.  k_wide_digits writes one 32-bit word per (window, point) -- bucket | sign << 31, or
-// kWideNoDigit -- and counts the entries of every partition; k_wide_scan turns the counts into
-// partition starts; k_wide_scatter moves record index | low bits | sign into the partitions (ranked
-// in LDS, one reservation per partition and block, leaving through LDS in partition order);
-// k_wide_sort_lo finishes a partition per block and writes the sorted entries (record index | sign)
-// and the bucket bounds.  Nothing is packed: an entry names record (w, j) of the table.
-constexpr u32 kWideNoDigit = 0xffffffffu;
-constexpr u32 kWideDigitPoints = 2048;
-constexpr u32 kWideScatterPoints = 4096;
-
-template <class C>
-__global__ __launch_bounds__(1024) void k_wide_digits(const u32* __restrict__ s0, const uint8_t* __restrict__ inf0, size_t n,
-                                                      int c, int n_windows, int lo_bits, u32 n_hi,
-                                                      u32* __restrict__ digits, u32* __restrict__ part_count) {
-  using Fr = typename C::Fr;
-  __shared__ u32 hist[kTwoMaxBins];
-  for (u32 q = threadIdx.x; q < n_hi; q += blockDim.x) hist[q] = 0;
-  __syncthreads();
-  const u32 half = 1u << (c - 1), mask = (1u << c) - 1;
-  for (u32 it = 0; it < kWideDigitPoints / 1024; it++) {
-    const size_t i = (size_t)blockIdx.x * kWideDigitPoints + (size_t)it * 1024 + threadIdx.x;
-    const bool live = i < n;
-    Fe k = fe_zero();
-    bool is_inf = true;
-    u32 flip = 0;
-    if (live) {
-      is_inf = inf0 && inf0[i];
-      k = fe_from_mont<Fr>(fe_load(s0 + i * 8));
-      // |k| <= r/2: use r - k with the point negated when that is the smaller value
-      Fe nk = fe_neg<Fr>(k);
-      bool gt = false, decided = false;
-#pragma unroll
-      for (int t = 7; t >= 0; t--) {
-        if (!decided && k.v[t] != nk.v[t]) {
-          gt = k.v[t] > nk.v[t];
-          decided = true;
-        }
-      }
-      if (gt) {
-        k = nk;
-        flip = 1;
-      }
-    }
-    u32 carry = 0;
-    for (int w = 0; w < n_windows; w++) {
-      const int bit = w * c, limb = bit >> 5, sh = bit & 31;
-      u32 raw = 0;
-      if (limb < 8) {
-        u32 lo = 0, hi = 0;
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-          lo = (t == limb) ? k.v[t] : lo;
-          hi = (t == limb + 1) ? k.v[t] : hi;
-        }
-        unsigned long long two = ((unsigned long long)hi << 32) | lo;
-        raw = (u32)(two >> sh) & mask;
-      }
-      const u32 v = raw + carry;
-      u32 mag, neg;
-      if (v > half) {
-        carry = 1;
-        mag = (1u << c) - v;
-        neg = 1;
-      } else {
-        carry = 0;
-        mag = v;
-        neg = 0;
-      }
-      const bool valid = live && !is_inf && mag != 0;
-      const u32 key = mag - 1;
-      if (live) digits[(size_t)w * n + i] = valid ? (key | ((neg ^ flip) << 31)) : kWideNoDigit;
-      lds_rank(hist, key >> lo_bits, valid);
-    }
-  }
-  __syncthreads();
-  for (u32 q = threadIdx.x; q < n_hi; q += blockDim.x)
-    if (hist[q]) atomicAdd(&part_count[q], hist[q]);
-}
-
-// one block: part_start = exclusive scan of part_count (n_hi <= kTwoMaxBins values), cursors cleared
-__global__ __launch_bounds__(1024) void k_wide_scan(const u32* __restrict__ part_count, u32 n_hi, u32* __restrict__ part_start,
-                                                    u32* __restrict__ cursor) {
-  __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
-  constexpr u32 kPer = kTwoMaxBins / kSmallThreads;
-  u32 v[kPer], mine = 0;
-#pragma unroll
-  for (u32 q = 0; q < kPer; q++) {
-    const u32 b = threadIdx.x * kPer + q;
-    v[q] = b < n_hi ? part_count[b] : 0u;
-    mine += v[q];
-  }
-  u32 total;
-  u32 at = block_exclusive_scan(mine, wave_sums, &total);
-#pragma unroll
-  for (u32 q = 0; q < kPer; q++) {
-    const u32 b = threadIdx.x * kPer + q;
-    if (b < n_hi) {
-      part_start[b] = at;
-      cursor[b] = 0;
-    }
-    at += v[q];
-  }
-}
-
-__global__ __launch_bounds__(1024) void k_wide_scatter(const u32* __restrict__ digits, const u32* __restrict__ part_start,
-                                                       size_t n, size_t tab_stride, size_t tab_off, int lo_bits,
-                                                       int idx_bits, u32 n_hi, u32* __restrict__ cursor,
-                                                       u32* __restrict__ words) {
-  __shared__ u32 hist[kTwoMaxBins], gbase[kTwoMaxBins], loff[kTwoMaxBins];
-  __shared__ u32 st_word[kWideScatterPoints], st_dst[kWideScatterPoints];
-  __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
-  const u32 w = blockIdx.y;
-  for (u32 q = threadIdx.x; q < n_hi; q += blockDim.x) hist[q] = 0;
-  __syncthreads();
-  constexpr int kIters = kWideScatterPoints / 1024;
-  constexpr u32 kPer = kTwoMaxBins / kSmallThreads;
-  const u32 lo_mask = (1u << lo_bits) - 1u;
-  u32 my_word[kIters], my_hi[kIters], my_rank[kIters];
-#pragma unroll
-  for (int it = 0; it < kIters; it++) {
-    const size_t i = (size_t)blockIdx.x * kWideScatterPoints + (size_t)it * 1024 + threadIdx.x;
-    const u32 d = i < n ? digits[(size_t)w * n + i] : kWideNoDigit;
-    const bool valid = d != kWideNoDigit;
-    const u32 key = d & 0x7fffffffu, bin = key >> lo_bits;
-    my_hi[it] = valid ? bin : n_hi;
-    my_word[it] = (u32)((size_t)w * tab_stride + tab_off + i) | ((key & lo_mask) << idx_bits) | (d & 0x80000000u);
-    my_rank[it] = lds_rank(hist, bin, valid);
-  }
-  __syncthreads();
-  // this block's entries ordered by partition (loff) and the slots it reserves in every partition
-  u32 mine = 0;
-#pragma unroll
-  for (u32 q = 0; q < kPer; q++) {
-    const u32 b = threadIdx.x * kPer + q;
-    mine += b < n_hi ? hist[b] : 0u;
-  }
-  u32 total;
-  u32 at = block_exclusive_scan(mine, wave_sums, &total);
-#pragma unroll
-  for (u32 q = 0; q < kPer; q++) {
-    const u32 b = threadIdx.x * kPer + q;
-    if (b < n_hi) {
-      const u32 cnt = hist[b];
-      loff[b] = at;
-      gbase[b] = cnt ? part_start[b] + atomicAdd(&cursor[b], cnt) : 0u;
-      at += cnt;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < kIters; it++)
-    if (my_hi[it] < n_hi) {
-      const u32 j = loff[my_hi[it]] + my_rank[it];
-      st_word[j] = my_word[it];
-      st_dst[j] = gbase[my_hi[it]] + my_rank[it];
-    }
-  __syncthreads();
-  for (u32 j = threadIdx.x; j < total; j += blockDim.x) words[st_dst[j]] = st_word[j];
-}
-
-// one block per partition: counting sort by the low bucket bits, bucket bounds
-__global__ __launch_bounds__(1024) void k_wide_sort_lo(const u32* __restrict__ words, const u32* __restrict__ part_count,
-                                                       const u32* __restrict__ part_start, int lo_bits, int idx_bits,
-                                                       u32* __restrict__ sorted_vals, u32* __restrict__ bucket_start,
-                                                       u32* __restrict__ bucket_end) {
-  __shared__ u32 hist[kTwoLo], off[kTwoLo];
-  __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
-  __shared__ u32 staged[kTwoIters * 1024];
-  const u32 h = blockIdx.x;
-  const u32 m = part_count[h], s = part_start[h];
-  const u32 n_lo = 1u << lo_bits, lo_mask = n_lo - 1u, idx_mask = (1u << idx_bits) - 1u;
-  if (threadIdx.x < kTwoLo) hist[threadIdx.x] = 0;
-  __syncthreads();
-  const bool cached = m <= (u32)kTwoIters * 1024u;
-  u32 my_word[kTwoIters], my_rank[kTwoIters];
-  if (cached) {
-#pragma unroll
-    for (int it = 0; it < kTwoIters; it++) {
-      const u32 p = (u32)it * 1024u + threadIdx.x;
-      const bool valid = p < m;
-      const u32 word = valid ? words[s + p] : 0u;
-      my_word[it] = word;
-      my_rank[it] = lds_rank(hist, (word >> idx_bits) & lo_mask, valid);
-    }
-  } else {
-    for (u32 p0 = 0; p0 < m; p0 += 1024u) {
-      const u32 p = p0 + threadIdx.x;
-      const bool valid = p < m;
-      const u32 word = valid ? words[s + p] : 0u;
-      lds_rank(hist, (word >> idx_bits) & lo_mask, valid);
-    }
-  }
-  __syncthreads();
-  u32 total;
-  const u32 mine = threadIdx.x < n_lo ? hist[threadIdx.x] : 0u;
-  const u32 before = block_exclusive_scan(mine, wave_sums, &total);
-  if (threadIdx.x < n_lo) {
-    off[threadIdx.x] = before;
-    const size_t gb = (size_t)h * n_lo + threadIdx.x;
-    bucket_start[gb] = s + before;
-    bucket_end[gb] = s + before + mine;
-  }
-  __syncthreads();
-  if (cached) {
-#pragma unroll
-    for (int it = 0; it < kTwoIters; it++) {
-      const u32 p = (u32)it * 1024u + threadIdx.x;
-      if (p < m) {
-        const u32 word = my_word[it];
-        staged[off[(word >> idx_bits) & lo_mask] + my_rank[it]] = (word & idx_mask) | (word & 0x80000000u);
-      }
-    }
-    __syncthreads();
-    for (u32 p = threadIdx.x; p < m; p += blockDim.x) sorted_vals[s + p] = staged[p];
-  } else {
-    // too many entries to keep: read them again, off[] now counts upwards as the cursor
-    for (u32 p0 = 0; p0 < m; p0 += 1024u) {
-      const u32 p = p0 + threadIdx.x;
-      const bool valid = p < m;
-      const u32 word = valid ? words[s + p] : 0u;
-      const u32 pos = lds_rank(off, (word >> idx_bits) & lo_mask, valid);
-      if (valid) sorted_vals[s + pos] = (word & idx_mask) | (word & 0x80000000u);
     }
   }
 }
@@ -2366,28 +2115,6 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     if (!p0.sel_half && !p1.sel_half && p0.n && p1.n && p0.group_lo > p1.group_lo) return hipErrorInvalidValue;
   }
   if (plan.tab && (!table || !table->rec)) return hipErrorInvalidValue;
-  if (plan.wide) {
-    if (p1.n || extra || !table->wide) return hipErrorInvalidValue;
-    const u32 n_hi = plan.n_buckets >> plan.lo_bits;
-    // counters live in the chunk-offset array, which is not written before the chunk table
-    u32* part_count = ws.choff;
-    u32* part_start = ws.choff + kTwoMaxBins;
-    u32* cursor = ws.choff + 2 * kTwoMaxBins;
-    if ((e = hipMemsetAsync(part_count, 0, kTwoMaxBins * sizeof(u32), st)) != hipSuccess) return e;
-    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_wide_digits<C>, dim3((unsigned)((n + kWideDigitPoints - 1) / kWideDigitPoints)),
-                                             dim3(1024), 0, st, p0.s, p0.inf, n, plan.c, plan.digit_windows, plan.lo_bits,
-                                             n_hi, ws.keys_b, part_count));
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_wide_scan, dim3(1), dim3(kSmallThreads), 0, st, part_count, n_hi, part_start, cursor);
-    hipLaunchKernelGGL(k_wide_scatter, dim3((unsigned)((n + kWideScatterPoints - 1) / kWideScatterPoints),
-                                            (unsigned)plan.digit_windows), dim3(1024), 0, st, ws.keys_b, part_start, n,
-                       table->stride, p0.tab_offset, plan.lo_bits, plan.idx_bits, n_hi, cursor, ws.keys_a);
-    hipLaunchKernelGGL(k_wide_sort_lo, dim3(n_hi), dim3(1024), 0, st, ws.keys_a, part_count, part_start, plan.lo_bits,
-                       plan.idx_bits, ws.vals_b, ws.bucket_start, ws.bucket_end);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if ((e = msm_chunk_table(plan, ws, st)) != hipSuccess) return e;
-    return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1, table->rec);
-  }
   if (plan.small) {
     // sorted entries and bucket bounds straight into the buffers the accumulation reads
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_small_front<C>, dim3((unsigned)plan.n_windows), dim3(kSmallThreads), 0, st,
@@ -2640,7 +2367,7 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
     if (ev_acc1 && (e = hipEventRecord(ev_acc1, st)) != hipSuccess) return e;
   } else {
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_chunk_sums<C>, dim3((unsigned)((plan.nc_cap + 127) / 128)), dim3(128),
-                                             0, st, points, ws.vals_b, ws.choff + nbt, ws.cval_b, ws.desc_b, ws.desc_s,
+                                             0, st, ws.packed, ws.vals_b, ws.choff + nbt, ws.cval_b, ws.desc_b, ws.desc_s,
                                              ws.bucket_end, ws.nch, nbt, plan.chunk, plan.nc_cap, idx_mask,
                                              (size_t)plan.entries, ws.buckets, ws.chunk_sums));
     if ((e = hipGetLastError()) != hipSuccess) return e;

@@ -126,19 +126,6 @@ size_t bp_bases_len(const bp_bases* b);
  * longer dependent chain on the GPU that only pays where the host core is slow.  No counterpart
  * in the reference (arkworks' msm_unchecked takes the bases fresh on every call). */
 int bp_bases_precompute(bp_bases* b);
-/* Optional: wide window tables of a registered base set (2^(16w) * P for w < 16: 1 KiB per base, one
- * lane per base, built once; at most 2^22 bases).  A sum over 2^16 .. 2^21 of these bases with no
- * second sum riding along (bp_msm_resident, bp_msm_resident_plus, bp_msm_resident_s_vector,
- * bp_batch_msm, bp_ipa_verify_msm, bp_range_agg_verify_msm) then reads record (w, j) for digit w of
- * scalar j, so that all sixteen digit windows feed ONE set of 32768 buckets: the bucket accumulation
- * is unchanged, the bucket reduction runs over one window instead of sixteen, no point is re-packed,
- * and the host adds nothing up (2^20 points: 1.38 -> 1.1 ms).  Points outside the set (the extras of
- * the verifier forms) go through the plain pipeline in the same call, and the two results are
- * added.  The static CRS of the commitment, verifier and polynomial-commitment MSMs
- * (src/poly_commit/types.rs:141, src/poly_commit/mod.rs:111,159, src/range/aggregate.rs:259) is the
- * case it is for; results are unchanged.  No counterpart in the reference (arkworks' msm_unchecked
- * takes the bases fresh on every call). */
-int bp_bases_precompute_wide(bp_bases* b);
 /* MSM over bases[offset .. offset+n) with host scalars (crs.gs[0..n] slices:
  * src/ipa/types.rs:81-82). */
 int bp_msm_resident(bp_ctx* ctx, const bp_bases* bases, size_t offset, size_t n,
