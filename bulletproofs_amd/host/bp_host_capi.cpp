@@ -769,3 +769,278 @@ int bph_poly_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_
 }
 
 }  // extern "C"
+
+// ---- polynomial commitment over several ranks ------------------------------------------------
+#include "bp_host_sharded.hpp"
+
+namespace {
+
+struct SpolyOut {
+  uint64_t *l, *r, *ar, *g, *commit, *eval, *halo_out, *halo_w;
+  double *prove_ms, *verify_ms;
+  int *ok_verify, *ok_lazy, *ok_halo;
+};
+
+// One rank's run of the flow of poly_roundtrip (statement, prove, verify, lazy_verify and, with a second
+// coefficient slice, the fold of the two deferred checks and its opening) over slices: gx, gy and the
+// coefficient vectors hold the elements rank, rank + world, ... of the whole vectors.  Outputs as
+// bph_poly_roundtrip; halo_w receives this rank's slice of the folded witness (n / world scalars).
+template <class Fq, class Fr, int CURVE>
+int spoly_roundtrip(bp_ctx* ctx, Exchange& ex, const uint64_t* gx, const uint64_t* gy, const uint64_t* h_gen_xy,
+                    const uint64_t* coeffs, const uint64_t* coeffs2, size_t n_total, const uint64_t* r_x, uint64_t seed_rand,
+                    uint64_t seed_chal, int tamper, const SpolyOut& o) {
+  using SP = ShardedPolyCommit<Fq, Fr, CURVE>;
+  using S = ScalarOps<Fr>;
+  typename SP::Crs crs;
+  crs.n = n_total; crs.rank = ex.rank; crs.world = ex.world;
+  const size_t nl = n_total / ex.world;
+  crs.gs = unpack(gx, gy, nullptr, nl);
+  auto pt = [&](int k) { Affine a; memcpy(a.x, h_gen_xy + 8 * k, 32); memcpy(a.y, h_gen_xy + 8 * k + 4, 32); a.inf = 0; return a; };
+  crs.h = pt(0); crs.gen = pt(1);
+  SP::register_bases(ctx, crs);
+  *o.ok_verify = *o.ok_lazy = *o.ok_halo = 0;
+  try {
+    std::vector<Scalar> p = unpack_s(coeffs, nl);
+    Scalar r, x;
+    memcpy(r.l, r_x, 32); memcpy(x.l, r_x + 4, 32);
+    auto st = SP::statement(ctx, crs, ex, p, r, x);
+    PolyProof proof;
+    SeededTranscript<Fr> t1(seed_chal);
+    SeededRandom<Fr> rng(seed_rand);
+    auto a0 = std::chrono::steady_clock::now();
+    Todo todo = SP::prove(ctx, crs, ex, st, p, r, t1, rng, proof);
+    auto a1 = std::chrono::steady_clock::now();
+    auto st_check = st;
+    if (tamper == 1) st_check.evaluation = S::add(st_check.evaluation, S::one());
+    PolyProof check_proof = proof;
+    if (tamper == 2 && !check_proof.L.empty()) { check_proof.L.pop_back(); check_proof.R.pop_back(); }
+    if (tamper == 3) { check_proof.L.push_back(st.commitment); check_proof.R.push_back(st.commitment); }
+    SeededTranscript<Fr> t2(seed_chal);
+    auto b0 = std::chrono::steady_clock::now();
+    *o.ok_verify = SP::verify(ctx, crs, ex, st_check, check_proof, t2) ? 1 : 0;
+    auto b1 = std::chrono::steady_clock::now();
+    *o.prove_ms = std::chrono::duration<double, std::milli>(a1 - a0).count();
+    *o.verify_ms = std::chrono::duration<double, std::milli>(b1 - b0).count();
+    std::vector<Todo> todos;
+    SeededTranscript<Fr> t3(seed_chal);
+    *o.ok_lazy = SP::lazy_verify(ctx, crs, st_check, todo.g, check_proof, t3, todos) ? 1 : 0;
+    const size_t k = proof.L.size();
+    for (size_t j = 0; j < k; j++) { memcpy(o.l + 12 * j, proof.L[j].xyz, 96); memcpy(o.r + 12 * j, proof.R[j].xyz, 96); }
+    memcpy(o.ar, proof.a.l, 32); memcpy(o.ar + 4, proof.r.l, 32);
+    memcpy(o.g, todo.g.x, 32); memcpy(o.g + 4, todo.g.y, 32); o.g[8] = todo.g.inf;
+    memcpy(o.commit, st.commitment.xyz, 96);
+    memcpy(o.eval, st.evaluation.l, 32);
+    if (coeffs2 && !tamper) {
+      std::vector<Scalar> p2 = unpack_s(coeffs2, nl);
+      auto st2 = SP::statement(ctx, crs, ex, p2, r, x);
+      PolyProof proof2;
+      SeededTranscript<Fr> t4(seed_chal + 7777);
+      SeededRandom<Fr> rng2(seed_rand + 7777);
+      Todo todo2 = SP::prove(ctx, crs, ex, st2, p2, r, t4, rng2, proof2);
+      SeededTranscript<Fr> t5(seed_chal + 7777);
+      bool ok = SP::lazy_verify(ctx, crs, st2, todo2.g, proof2, t5, todos) && todos.size() == 2;
+      SeededTranscript<Fr> tc(seed_chal ^ 0xA1FAull);
+      Scalar alpha = tc.verifier_scalar(), x2 = tc.verifier_scalar();
+      std::vector<Scalar> w = SP::fold_todos_witness(ctx, crs, todos, alpha);
+      auto fst = SP::fold_todos_statement(ctx, todos, alpha, x2);
+      auto wst = SP::statement(ctx, crs, ex, w, S::zero(), x2);
+      ok = ok && memcmp(wst.commitment.xyz, fst.commitment.xyz, 96) == 0 && wst.evaluation == fst.evaluation;
+      PolyProof proof3;
+      SeededTranscript<Fr> t6(seed_chal + 9999);
+      SeededRandom<Fr> rng3(seed_rand + 9999);
+      SP::prove(ctx, crs, ex, fst, w, S::zero(), t6, rng3, proof3);
+      SeededTranscript<Fr> t7(seed_chal + 9999);
+      ok = SP::verify(ctx, crs, ex, fst, proof3, t7) && ok;
+      *o.ok_halo = ok ? 1 : 0;
+      if (o.halo_out) {
+        uint64_t* q = o.halo_out;
+        auto put_proof = [&](const PolyProof& pf) {
+          for (size_t j = 0; j < k; j++) { memcpy(q, pf.L[j].xyz, 96); q += 12; }
+          for (size_t j = 0; j < k; j++) { memcpy(q, pf.R[j].xyz, 96); q += 12; }
+          memcpy(q, pf.a.l, 32); memcpy(q + 4, pf.r.l, 32); q += 8;
+        };
+        put_proof(proof2);
+        memcpy(q, todo2.g.x, 32); memcpy(q + 4, todo2.g.y, 32); q[8] = todo2.g.inf; q += 9;
+        memcpy(q, st2.commitment.xyz, 96); q += 12;
+        memcpy(q, st2.evaluation.l, 32); q += 4;
+        memcpy(q, alpha.l, 32); memcpy(q + 4, x2.l, 32); q += 8;
+        memcpy(q, fst.commitment.xyz, 96); q += 12;
+        memcpy(q, fst.evaluation.l, 32); q += 4;
+        put_proof(proof3);
+      }
+      if (o.halo_w) memcpy(o.halo_w, w[0].l, 32 * w.size());
+    }
+  } catch (...) {
+    bp_bases_free(crs.bases);
+    throw;
+  }
+  bp_bases_free(crs.bases);
+  return 0;
+}
+
+template <class F>
+int spoly_dispatch(int curve, F&& f) {
+  try {
+    return f(curve);
+  } catch (const VerificationError&) {
+    return BPH_E_VERIFY;
+  } catch (const std::invalid_argument&) {
+    return BP_E_ARG;
+  } catch (const std::exception&) {
+    return BP_E_HIP;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// One rank of the polynomial-commitment flow over `world` ranks (bp_host_sharded.hpp); `gather` is the
+// caller's all-gather of small host packets: gather(user, mine, len_u64, all) fills all[r * len ..] with rank
+// r's packet on every rank and returns 0.  gx, gy: this rank's n_total / world generators (rank, rank +
+// world, ...); coeffs, coeffs2 (may be NULL: no second opening and no fold): the same slice of each
+// coefficient vector, zero-padded to the slice length.  Outputs as bph_poly_roundtrip, identical on every
+// rank, except halo_w: this rank's slice of the folded witness.
+int bph_spoly_roundtrip(bp_ctx* ctx, int curve, size_t rank, size_t world, int (*gather)(void*, const uint64_t*, size_t, uint64_t*),
+                        void* user, const uint64_t* gx, const uint64_t* gy, const uint64_t* h_gen_xy, const uint64_t* coeffs,
+                        const uint64_t* coeffs2, size_t n_total, const uint64_t* r_x, uint64_t seed_rand, uint64_t seed_chal,
+                        int tamper, uint64_t* out_l, uint64_t* out_r, uint64_t* out_ar, uint64_t* out_g, uint64_t* out_commit,
+                        uint64_t* out_eval, double* prove_ms, double* verify_ms, int* ok_verify, int* ok_lazy, int* ok_halo,
+                        uint64_t* halo_out, uint64_t* halo_w) {
+  if (!ctx || world == 0 || rank >= world || (world > 1 && !gather)) return BP_E_ARG;
+  CallbackExchange ex;
+  ex.rank = rank; ex.world = world; ex.fn = gather; ex.user = user;
+  SpolyOut o{out_l, out_r, out_ar, out_g, out_commit, out_eval, halo_out, halo_w, prove_ms, verify_ms, ok_verify, ok_lazy, ok_halo};
+  return spoly_dispatch(curve, [&](int c) {
+    if (c == BP_SECP256K1)
+      return spoly_roundtrip<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(ctx, ex, gx, gy, h_gen_xy, coeffs, coeffs2, n_total, r_x, seed_rand,
+                                                                    seed_chal, tamper, o);
+    if (c == BP_VESTA)
+      return spoly_roundtrip<VestaFq, VestaFr, BP_VESTA>(ctx, ex, gx, gy, h_gen_xy, coeffs, coeffs2, n_total, r_x, seed_rand, seed_chal,
+                                                        tamper, o);
+    return (int)BP_E_CURVE;
+  });
+}
+
+// The same flow with the ranks as threads of this process: rank r runs on HIP device first_device +
+// r mod n_devices with a context of its own, the exchange is a barrier over a shared buffer.  Takes the whole
+// vectors (gx, gy: n generators; coeffs: n_coeffs <= n scalars, zero-padded; halo != 0: the second opening is
+// of the reversed coefficient vector, as in bph_poly_roundtrip) and cuts the slices itself.  Returns rank 0's
+// outputs after checking that every rank produced the same; halo_w: the whole folded witness (n scalars).
+// prove_ms / verify_ms: the slowest rank's.
+int bph_spoly_roundtrip_threads(int first_device, int n_devices, size_t world, int curve, const uint64_t* gx, const uint64_t* gy,
+                                const uint64_t* h_gen_xy, const uint64_t* coeffs, size_t n_coeffs, size_t n, const uint64_t* r_x,
+                                uint64_t seed_rand, uint64_t seed_chal, int tamper, int halo, uint64_t* out_l, uint64_t* out_r,
+                                uint64_t* out_ar, uint64_t* out_g, uint64_t* out_commit, uint64_t* out_eval, double* prove_ms,
+                                double* verify_ms, int* ok_verify, int* ok_lazy, int* ok_halo, uint64_t* halo_out, uint64_t* halo_w) {
+  if (world == 0 || (world & (world - 1)) || world > 64 || n == 0 || (n & (n - 1)) || n < world || n_coeffs > n || n_devices < 1)
+    return BP_E_ARG;
+  size_t k = 0;
+  while (((size_t)1 << k) < n) k++;
+  const size_t nl = n / world, halo_len = 48 * k + 65, kk = k ? k : 1;
+  struct RankOut {
+    std::vector<uint64_t> l, r, ar, g, commit, eval, halo_out, halo_w;
+    double prove_ms = 0, verify_ms = 0;
+    int ok_verify = 0, ok_lazy = 0, ok_halo = 0, rc = BP_E_HIP;
+  };
+  std::vector<RankOut> outs(world);
+  LocalExchangeHub hub(world);
+  std::vector<std::thread> threads;
+  for (size_t rank = 0; rank < world; rank++) {
+    threads.emplace_back([&, rank] {
+      RankOut& ro = outs[rank];
+      ro.l.assign(12 * kk, 0); ro.r.assign(12 * kk, 0); ro.ar.assign(8, 0); ro.g.assign(9, 0); ro.commit.assign(12, 0);
+      ro.eval.assign(4, 0); ro.halo_out.assign(halo_len, 0); ro.halo_w.assign(4 * nl, 0);
+      // this rank's slices: elements rank, rank + world, ...
+      std::vector<uint64_t> sgx(4 * nl), sgy(4 * nl), sc(4 * nl, 0), sc2(4 * nl, 0);
+      for (size_t j = 0; j < nl; j++) {
+        const size_t i = rank + world * j;
+        memcpy(&sgx[4 * j], gx + 4 * i, 32); memcpy(&sgy[4 * j], gy + 4 * i, 32);
+        if (i < n_coeffs) memcpy(&sc[4 * j], coeffs + 4 * i, 32);
+        // the reversed vector (n_coeffs elements) zero-padded: element i is coeffs[n_coeffs - 1 - i]
+        if (i < n_coeffs) memcpy(&sc2[4 * j], coeffs + 4 * (n_coeffs - 1 - i), 32);
+      }
+      bp_ctx* ctx = nullptr;
+      if (bp_init(first_device + (int)(rank % (size_t)n_devices), &ctx) != BP_OK) { ro.rc = BP_E_HIP; hub.abort(); return; }
+      LocalExchange ex(&hub, rank);
+      SpolyOut o{ro.l.data(), ro.r.data(), ro.ar.data(), ro.g.data(), ro.commit.data(), ro.eval.data(), ro.halo_out.data(),
+                 ro.halo_w.data(), &ro.prove_ms, &ro.verify_ms, &ro.ok_verify, &ro.ok_lazy, &ro.ok_halo};
+      ro.rc = spoly_dispatch(curve, [&](int c) {
+        if (c == BP_SECP256K1)
+          return spoly_roundtrip<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(ctx, ex, sgx.data(), sgy.data(), h_gen_xy, sc.data(),
+                                                                        halo ? sc2.data() : nullptr, n, r_x, seed_rand, seed_chal,
+                                                                        tamper, o);
+        if (c == BP_VESTA)
+          return spoly_roundtrip<VestaFq, VestaFr, BP_VESTA>(ctx, ex, sgx.data(), sgy.data(), h_gen_xy, sc.data(),
+                                                            halo ? sc2.data() : nullptr, n, r_x, seed_rand, seed_chal, tamper, o);
+        return (int)BP_E_CURVE;
+      });
+      if (ro.rc != BP_OK) hub.abort();
+      bp_shutdown(ctx);
+    });
+  }
+  for (auto& t : threads) t.join();
+  for (size_t rank = 0; rank < world; rank++)
+    if (outs[rank].rc != BP_OK) return outs[rank].rc;
+  const RankOut& z = outs[0];
+  *prove_ms = *verify_ms = 0;
+  for (size_t rank = 0; rank < world; rank++) {
+    const RankOut& ro = outs[rank];
+    if (ro.l != z.l || ro.r != z.r || ro.ar != z.ar || ro.g != z.g || ro.commit != z.commit || ro.eval != z.eval ||
+        ro.halo_out != z.halo_out || ro.ok_verify != z.ok_verify || ro.ok_lazy != z.ok_lazy || ro.ok_halo != z.ok_halo)
+      return BP_E_STATE;  // the ranks disagree
+    if (ro.prove_ms > *prove_ms) *prove_ms = ro.prove_ms;
+    if (ro.verify_ms > *verify_ms) *verify_ms = ro.verify_ms;
+    if (halo_w)
+      for (size_t j = 0; j < nl; j++) memcpy(halo_w + 4 * (rank + world * j), &ro.halo_w[4 * j], 32);
+  }
+  memcpy(out_l, z.l.data(), 96 * k); memcpy(out_r, z.r.data(), 96 * k);
+  memcpy(out_ar, z.ar.data(), 64); memcpy(out_g, z.g.data(), 72); memcpy(out_commit, z.commit.data(), 96);
+  memcpy(out_eval, z.eval.data(), 32);
+  if (halo_out) memcpy(halo_out, z.halo_out.data(), 8 * halo_len);
+  *ok_verify = z.ok_verify; *ok_lazy = z.ok_lazy; *ok_halo = z.ok_halo;
+  return BP_OK;
+}
+
+}  // extern "C"
+
+// ---- sums of a handful of results on the host ----------------------------------------------------
+extern "C" {
+
+// out = sum of `count` group results (normalised Jacobian, 12 u64 each, as every entry point of the
+// library returns them), normalised: the per-rank shares of a sharded round's L and R are added here
+// rather than by a launch chain on the device.  No device call.
+int bph_points_sum(int curve, const uint64_t* xyz, size_t count, uint64_t out[12]) {
+  if (!out || (count && !xyz)) return BP_E_ARG;
+  auto run = [&](auto fq, auto fr) {
+    using Fq = decltype(fq);
+    using Fr = decltype(fr);
+    HXyzz acc = hx_identity<Fq>();
+    for (size_t i = 0; i < count; i++) {
+      Projective p;
+      memcpy(p.xyz, xyz + 12 * i, 96);
+      acc = hx_add<Fq>(acc, PointOps<Fq, Fr>::lift(p));
+    }
+    hx_to_xyz<Fq>(acc, out);
+  };
+  if (curve == BP_SECP256K1) run(Secp256k1Fq{}, Secp256k1Fr{});
+  else if (curve == BP_VESTA) run(VestaFq{}, VestaFr{});
+  else return BP_E_CURVE;
+  return BP_OK;
+}
+
+// out = sum of `count` scalars (Montgomery limbs)
+int bph_scalars_sum(int curve, const uint64_t* s, size_t count, uint64_t out[4]) {
+  if (!out || (count && !s)) return BP_E_ARG;
+  if (curve != BP_SECP256K1 && curve != BP_VESTA) return BP_E_CURVE;
+  Scalar acc{{0, 0, 0, 0}};
+  for (size_t i = 0; i < count; i++) {
+    Scalar v;
+    memcpy(v.l, s + 4 * i, 32);
+    acc = curve == BP_SECP256K1 ? ScalarOps<Secp256k1Fr>::add(acc, v) : ScalarOps<VestaFr>::add(acc, v);
+  }
+  memcpy(out, acc.l, 32);
+  return BP_OK;
+}
+
+}  // extern "C"

@@ -230,3 +230,137 @@ def range_bench_inputs(ctx: Context, m, n_bits, seed):
     gamma = rng.integers(0, 1 << 64, (m, 4), dtype=np.uint64)
     gamma[:, 3] &= np.uint64((1 << 63) - 1)
     return gs, hs, ugh, values, gamma
+
+
+# ---- polynomial commitment over several ranks (bp_host_sharded.hpp) ---------------------------------
+_GATHER = C.CFUNCTYPE(ci, vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_uint64))
+hlib.bph_spoly_roundtrip.restype = ci
+hlib.bph_spoly_roundtrip.argtypes = [vp, ci, sz, sz, _GATHER, vp, vp, vp, vp, vp, vp, sz, vp, C.c_uint64, C.c_uint64, ci, vp, vp, vp, vp,
+                                     vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci), C.POINTER(ci),
+                                     C.POINTER(ci), vp, vp]
+hlib.bph_spoly_roundtrip_threads.restype = ci
+hlib.bph_spoly_roundtrip_threads.argtypes = [ci, ci, sz, ci, vp, vp, vp, vp, sz, sz, vp, C.c_uint64, C.c_uint64, ci, ci, vp, vp, vp, vp,
+                                             vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci), C.POINTER(ci),
+                                             C.POINTER(ci), vp, vp]
+
+
+def _poly_outputs(k, n_w, want_halo):
+    L = np.zeros((max(k, 1), 12), dtype=np.uint64)
+    R = np.zeros((max(k, 1), 12), dtype=np.uint64)
+    ar, g = np.zeros((2, 4), dtype=np.uint64), np.zeros(9, dtype=np.uint64)
+    com, ev = np.zeros(12, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    ho = np.zeros(48 * k + 65, dtype=np.uint64) if want_halo else None
+    hw = np.zeros((n_w, 4), dtype=np.uint64) if want_halo else None
+    return L, R, ar, g, com, ev, ho, hw
+
+
+def _poly_result(k, L, R, ar, g, com, ev, ho, hw, tp, tv, okv, okl, okh):
+    res = dict(L=L[:k], R=R[:k], a=ar[0], r=ar[1], g=g, commitment=com, evaluation=ev, prove_ms=tp.value, verify_ms=tv.value,
+               verify_ok=bool(okv.value), lazy_ok=bool(okl.value), halo_ok=bool(okh.value))
+    if ho is not None:
+        pos = [0]
+
+        def take(cnt, shape=None):
+            v = ho[pos[0]:pos[0] + cnt]
+            pos[0] += cnt
+            return v if shape is None else v.reshape(shape)
+
+        second = dict(L=take(12 * k, (k, 12)), R=take(12 * k, (k, 12)), a=take(4), r=take(4), g=take(9), commitment=take(12),
+                      evaluation=take(4))
+        folded = dict(alpha=take(4), x=take(4), commitment=take(12), evaluation=take(4))
+        folded.update(L=take(12 * k, (k, 12)), R=take(12 * k, (k, 12)), a=take(4), r=take(4), witness=hw)
+        res.update(second=second, folded=folded)
+    return res
+
+
+def sharded_poly_roundtrip_threads(curve, gs, h_gen_xy, coeffs, r, x, world, seed_rand=1, seed_chal=2, tamper=False, halo=True,
+                                   first_device=0, n_devices=1):
+    """poly_commit_roundtrip with the vectors spread over `world` ranks by residue class of the index, the ranks
+    being threads of this process with a context each on devices first_device .. first_device + n_devices - 1
+    (round robin): same arguments and same result dictionary; `witness` of the folded statement is the whole
+    vector, interleaved from the ranks' slices."""
+    gx, gy, _ = _pts(gs)
+    n = gx.shape[0]
+    assert n & (n - 1) == 0
+    k = n.bit_length() - 1
+    coeffs = _f(coeffs)
+    rx = np.concatenate([_f(r).reshape(4), _f(x).reshape(4)])
+    h_gen_xy = np.ascontiguousarray(h_gen_xy, dtype=np.uint64).reshape(16)
+    want_halo = bool(halo) and not tamper
+    L, R, ar, g, com, ev, ho, hw = _poly_outputs(k, n, want_halo)
+    tp, tv, okv, okl, okh = C.c_double(), C.c_double(), ci(), ci(), ci()
+    rc = hlib.bph_spoly_roundtrip_threads(first_device, n_devices, world, curve, _p(gx), _p(gy), _p(h_gen_xy), _p(coeffs),
+                                          coeffs.shape[0], n, _p(rx), seed_rand, seed_chal, int(tamper), int(want_halo), _p(L), _p(R),
+                                          _p(ar), _p(g), _p(com), _p(ev), C.byref(tp), C.byref(tv), C.byref(okv), C.byref(okl),
+                                          C.byref(okh), _p(ho), _p(hw))
+    if rc:
+        raise RuntimeError(f"bph_spoly_roundtrip_threads rc={rc}")
+    return _poly_result(k, L, R, ar, g, com, ev, ho, hw, tp, tv, okv, okl, okh)
+
+
+def sharded_poly_roundtrip(ctx: Context, curve, gs_slice, h_gen_xy, coeffs_slice, coeffs2_slice, n_total, r, x, rank, world, gather,
+                           seed_rand=1, seed_chal=2, tamper=False):
+    """One rank of the same flow, the ranks being processes: gs_slice and the coefficient slices hold the
+    elements rank, rank + world, ... of the whole vectors (n_total / world each, zero-padded); coeffs2_slice
+    may be None (no second opening, no fold).  gather(packet: uint64 array) -> (world, len) uint64 array is
+    the caller's all-gather of small host packets (see sharded.host_gather).  Every rank returns the same
+    dictionary, except `witness` of the folded statement: this rank's slice."""
+    gx, gy, _ = _pts(gs_slice)
+    nl = gx.shape[0]
+    assert nl * world == n_total and n_total & (n_total - 1) == 0
+    k = n_total.bit_length() - 1
+    c1 = _f(coeffs_slice)
+    c2 = None if coeffs2_slice is None else _f(coeffs2_slice)
+    assert c1.shape[0] == nl and (c2 is None or c2.shape[0] == nl)
+    rx = np.concatenate([_f(r).reshape(4), _f(x).reshape(4)])
+    h_gen_xy = np.ascontiguousarray(h_gen_xy, dtype=np.uint64).reshape(16)
+    want_halo = c2 is not None and not tamper
+    L, R, ar, g, com, ev, ho, hw = _poly_outputs(k, nl, want_halo)
+    tp, tv, okv, okl, okh = C.c_double(), C.c_double(), ci(), ci(), ci()
+    failure = []
+
+    def cb(_user, mine, length, out):
+        try:
+            packet = np.ctypeslib.as_array(mine, shape=(length,)).copy()
+            got = np.ascontiguousarray(gather(packet), dtype=np.uint64).reshape(world * length)
+            np.ctypeslib.as_array(out, shape=(world * length,))[:] = got
+            return 0
+        except Exception as e:  # an exception must not cross the C frames
+            failure.append(e)
+            return 1
+
+    cfn = _GATHER(cb)
+    rc = hlib.bph_spoly_roundtrip(ctx.h, curve, rank, world, cfn, None, _p(gx), _p(gy), _p(h_gen_xy), _p(c1), _p(c2), n_total, _p(rx),
+                                  seed_rand, seed_chal, int(tamper), _p(L), _p(R), _p(ar), _p(g), _p(com), _p(ev), C.byref(tp),
+                                  C.byref(tv), C.byref(okv), C.byref(okl), C.byref(okh), _p(ho), _p(hw))
+    if failure:
+        raise failure[0]
+    if rc:
+        raise RuntimeError(f"bph_spoly_roundtrip rc={rc}")
+    return _poly_result(k, L, R, ar, g, com, ev, ho, hw, tp, tv, okv, okl, okh)
+
+
+hlib.bph_points_sum.restype = ci
+hlib.bph_points_sum.argtypes = [ci, vp, sz, vp]
+hlib.bph_scalars_sum.restype = ci
+hlib.bph_scalars_sum.argtypes = [ci, vp, sz, vp]
+
+
+def points_sum(curve, xyz):
+    """sum of group results (count x 12 u64, normalised Jacobian) on the host, normalised; needs no GPU"""
+    xyz = np.ascontiguousarray(xyz, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros(12, dtype=np.uint64)
+    rc = hlib.bph_points_sum(curve, _p(xyz), xyz.shape[0], _p(out))
+    if rc:
+        raise RuntimeError(f"bph_points_sum rc={rc}")
+    return out
+
+
+def scalars_sum(curve, v):
+    """sum of scalars (count x 4 u64, Montgomery limbs) on the host; needs no GPU"""
+    v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    rc = hlib.bph_scalars_sum(curve, _p(v), v.shape[0], _p(out))
+    if rc:
+        raise RuntimeError(f"bph_scalars_sum rc={rc}")
+    return out

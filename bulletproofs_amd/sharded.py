@@ -116,6 +116,25 @@ def dist_gather(dist, device="cuda"):
     return gather
 
 
+def host_gather(dist, group=None):
+    """gather(packet) -> (world, len(packet)) uint64 array over a torch.distributed group whose backend
+    takes CPU tensors (gloo): the packets of a sharded argument are results that have just arrived on the
+    host, so they are exchanged there, without a trip to the device and back.  With an RCCL-only job, create
+    the group with dist.new_group(backend="gloo") and pass it here."""
+    import numpy as np
+    import torch
+
+    world = dist.get_world_size(group)
+
+    def gather(packet):
+        src = torch.from_numpy(np.ascontiguousarray(packet, dtype=np.uint64).view(np.int64))
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src, group=group)
+        return torch.stack(parts).numpy().view(np.uint64).reshape(world, -1)
+
+    return gather
+
+
 class ShardedIpa:
     """The round loop of ipa::prove (src/ipa/mod.rs:33-95) or poly_commit::prove
     (src/poly_commit/mod.rs:69-105) with the vectors spread over `world` GPUs by residue class of the
@@ -131,8 +150,13 @@ class ShardedIpa:
     combine_lr, local_tail / begin_tail) so that a single process can drive several shards in
     lockstep; round_lr and round_fold put them together around `gather`."""
 
-    def __init__(self, ctx, curve, variant, gs, hs, a, b, rank=0, world=1, gather=None, u_xy=None):
+    def __init__(self, ctx, curve, variant, gs, hs, a, b, rank=0, world=1, gather=None, u_xy=None, sum_points=None,
+                 sum_scalars=None):
+        """sum_points(curve, (world, 12) results) -> 12 u64 and sum_scalars(curve, (world, 4)) -> 4 u64 default to
+        the host sums of libbp_host (bph_points_sum, bph_scalars_sum); tests may inject stand-ins."""
         import numpy as np
+
+        self.sum_points, self.sum_scalars = sum_points, sum_scalars
 
         self.np = np
         n = len(a)
@@ -170,22 +194,29 @@ class ShardedIpa:
         return self.np.concatenate([L, R, cl, cr])
 
     def combine_lr(self, packets):
-        """sums of the shares: points by an MSM with scalars one, field elements by bp_sum"""
+        """sums of the shares, on the host: `world` point additions per cross term (bph_points_sum) and the
+        two field sums; no launch and no copy for values that have just arrived from the device"""
         np = self.np
         packets = np.ascontiguousarray(packets, dtype=np.uint64).reshape(self.world, 32)
         if self.world == 1:
             p = packets[0]
             return p[0:12].copy(), p[12:24].copy(), p[24:28].copy(), p[28:32].copy()
-        ones = np.tile(self.one, (self.world, 1))
-        out = []
-        for off in (0, 12):
-            x = np.ascontiguousarray(packets[:, off:off + 4])
-            y = np.ascontiguousarray(packets[:, off + 4:off + 8])
-            inf = (~packets[:, off + 8:off + 12].any(axis=1)).astype(np.uint8)  # Z = 0: the identity
-            out.append(self.ctx.msm_unchecked(self.curve, (x, y, inf), ones))
-        cl = self.ctx.sum(self.curve, np.ascontiguousarray(packets[:, 24:28]))
-        cr = self.ctx.sum(self.curve, np.ascontiguousarray(packets[:, 28:32]))
-        return out[0], out[1], cl, cr
+        return (self._sum_points(packets[:, 0:12]), self._sum_points(packets[:, 12:24]),
+                self._sum_scalars(packets[:, 24:28]), self._sum_scalars(packets[:, 28:32]))
+
+    def _sum_points(self, xyz):
+        if self.sum_points is not None:
+            return self.sum_points(self.curve, xyz)
+        from .host_mirror import points_sum
+
+        return points_sum(self.curve, xyz)
+
+    def _sum_scalars(self, v):
+        if self.sum_scalars is not None:
+            return self.sum_scalars(self.curve, v)
+        from .host_mirror import scalars_sum
+
+        return scalars_sum(self.curve, v)
 
     def round_lr(self):
         if self.wants_tail:

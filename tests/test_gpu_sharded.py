@@ -210,3 +210,134 @@ def test_fold_todos_witness_shards_interleave_to_the_whole(ctx, c, k, world):
     for rank in range(world):
         got = fold_todos_witness_shard(ctx, c.id, CH, CHI, W, rank, world)
         assert np.array_equal(got, full[rank::world]), (rank, world)
+
+
+# ---- the polynomial commitment over several ranks (bp_host_sharded.hpp) ---------------------------
+
+def _poly_inputs(coracle, c, k, n_coeffs, seed):
+    from test_gpu_configs import gen_points, rand_scalars, xy8
+
+    rng = o.SplitMix64(seed)
+    G = gen_points(coracle, c, rng, 1 << k)
+    hg = np.stack([xy8(o.scalar_mul(rng.field(c.n), c.g, c), c), xy8(c.g, c)])
+    coeffs = rand_scalars(seed + 1, n_coeffs)
+    r, x = rand_scalars(seed + 2, 2)
+    return G, hg, coeffs, r, x
+
+
+def _assert_same_flow(got, exp):
+    for key in ("L", "R", "a", "r", "g", "commitment", "evaluation"):
+        assert np.array_equal(got[key], exp[key]), key
+    assert got["verify_ok"] == exp["verify_ok"] and got["lazy_ok"] == exp["lazy_ok"] and got["halo_ok"] == exp["halo_ok"]
+    if "second" in exp:
+        for part in ("second", "folded"):
+            for key, v in exp[part].items():
+                assert np.array_equal(got[part][key], v), (part, key)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("k,n_coeffs,world", [(12, (1 << 12) - 37, 4), (12, 1 << 12, 8), (3, 8, 8), (5, 20, 2), (4, 16, 1)])
+def test_sharded_poly_commit_equals_the_single_gpu_flow(ctx, coracle, c, k, n_coeffs, world):
+    """commit -> open -> verify -> lazy_verify -> fold of two deferred checks -> opening of the folded statement
+    (src/poly_commit/mod.rs:45-262, src/poly_commit/types.rs:137-151) with the vectors spread over `world`
+    ranks (threads with a context each, here all on one GPU): every message -- the commitments and
+    evaluations, all L_j, R_j, a, r, the folded generators, the folded witness and statement -- equals the
+    single-GPU driver's, the first opening also the C oracle's; world = 8 on 8 elements starts with the
+    replicated tail"""
+    from bulletproofs_amd import host_mirror
+
+    G, hg, coeffs, r, x = _poly_inputs(coracle, c, k, n_coeffs, 0x5A4D + 16 * k + world + c.id)
+    exp = host_mirror.poly_commit_roundtrip(ctx, c.id, G, hg, coeffs, r, x, seed_rand=5, seed_chal=6)
+    assert exp["verify_ok"] and exp["lazy_ok"] and exp["halo_ok"]
+    got = host_mirror.sharded_poly_roundtrip_threads(c.id, G, hg, coeffs, r, x, world, seed_rand=5, seed_chal=6)
+    _assert_same_flow(got, exp)
+    ora = coracle.poly_prove(c.id, G, hg, coeffs, r, x, 5, 6, threads=coracle.max_threads())
+    for key in ("L", "R", "a", "r", "g"):
+        assert np.array_equal(got[key], ora[key]), key
+    # a wrong evaluation and proofs of another shape are rejected by every rank
+    for mode in (1, 2, 3):
+        bad = host_mirror.sharded_poly_roundtrip_threads(c.id, G, hg, coeffs, r, x, world, seed_rand=5, seed_chal=6, tamper=mode)
+        assert not bad["verify_ok"] and not bad["lazy_ok"]
+
+
+def test_config5_sharded_poly_commit_2_20_over_8_ranks(ctx, coracle):
+    """the degree-2^20 - 1 opening with the halo fold over eight ranks (BASELINE config 5's split) against the
+    single-GPU flow, which test_gpu_configs.py checks against the C oracle message by message"""
+    from bulletproofs_amd import host_mirror
+
+    c = o.SECP256K1
+    G, hg, coeffs, r, x = _poly_inputs(coracle, c, 20, 1 << 20, 0x5A4D20)
+    exp = host_mirror.poly_commit_roundtrip(ctx, c.id, G, hg, coeffs, r, x, seed_rand=5, seed_chal=6)
+    assert exp["verify_ok"] and exp["lazy_ok"] and exp["halo_ok"]
+    got = host_mirror.sharded_poly_roundtrip_threads(c.id, G, hg, coeffs, r, x, 8, seed_rand=5, seed_chal=6)
+    _assert_same_flow(got, exp)
+
+
+def _spoly_worker(rank, world, port, q):
+    try:
+        import sys
+
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch.distributed as dist
+
+        import bulletproofs_amd as bp
+        import c_oracle
+        from bulletproofs_amd import host_mirror
+        from bulletproofs_amd.sharded import host_gather
+
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        c = o.SECP256K1
+        k = 10
+        n = 1 << k
+        G, hg, coeffs, r, x = _poly_inputs(c_oracle.COracle(), c, k, n - 5, 0x90100)
+        full = np.zeros((n, 4), dtype=np.uint64)
+        full[:n - 5] = coeffs
+        rev = np.zeros((n, 4), dtype=np.uint64)
+        rev[:n - 5] = coeffs[::-1]
+        ctx = bp.Context(0)
+        sl = slice(rank, None, world)
+        got = host_mirror.sharded_poly_roundtrip(ctx, c.id, (G[0][sl], G[1][sl], None), hg, full[sl], rev[sl], n, r, x, rank, world,
+                                                 host_gather(dist), seed_rand=5, seed_chal=6)
+        exp = host_mirror.poly_commit_roundtrip(ctx, c.id, G, hg, coeffs, r, x, seed_rand=5, seed_chal=6)
+        exp["folded"]["witness"] = exp["folded"]["witness"][sl]  # a rank returns its slice of the folded witness
+        _assert_same_flow(got, exp)
+        ctx.close()
+        q.put((rank, True))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as exc:
+        q.put((rank, repr(exc)))
+        raise
+
+
+def test_sharded_poly_commit_two_processes_over_gloo():
+    """the same flow with the ranks as two processes that share this GPU and exchange their packets over a
+    real gloo group (host buffers, all_gather): each rank's result equals the single-GPU flow's"""
+    import torch.multiprocessing as mp
+
+    mctx = mp.get_context("spawn")
+    q = mctx.Queue()
+    port = 32500 + (os.getpid() % 2000)
+    procs = [mctx.Process(target=_spoly_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert results == [(0, True), (1, True)], results
+
+
+@pytest.mark.parametrize("k,ranks", [(14, 4), (16, 8)])
+def test_native_sharded_poly_example(k, ranks):
+    """bulletproofs_amd/host/sharded_poly: the sharded polynomial-commitment flow from C++ without Python
+    (threads with a context each on as many devices as there are), compared inside the program with the same
+    flow on one context"""
+    exe = os.path.join(ROOT, "bulletproofs_amd", "host", "sharded_poly")
+    assert os.path.exists(exe), "build the host examples first (__graft_entry__.build)"
+    res = subprocess.run([exe, str(k), str(ranks)], capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["equal"] is True and line["verified"] is True and line["ranks"] == ranks and line["log2n"] == k

@@ -193,7 +193,7 @@ def _ipa_worker(rank, world, port, variant, q):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import bp_oracle as oo
-        from bulletproofs_amd.sharded import ShardedIpa, dist_gather
+        from bulletproofs_amd.sharded import ShardedIpa, host_gather
         from gen_golden import ipa_inputs
 
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -204,7 +204,7 @@ def _ipa_worker(rank, world, port, variant, q):
         u = oo.scalar_mul(31337, c.g, c)
         u_xy = oo.pack_field([u[0], u[1]], c.p).reshape(8)
         s = ShardedIpa(_OracleCtx(oo, c), c.id, variant, oo.pack_points(g, c), oo.pack_points(h, c) if variant == 0 else None,
-                       oo.pack_field(a, c.n), oo.pack_field(b, c.n), rank=rank, world=world, gather=dist_gather(dist, "cpu"),
+                       oo.pack_field(a, c.n), oo.pack_field(b, c.n), rank=rank, world=world, gather=host_gather(dist),
                        u_xy=u_xy)
         gs, hs, av, bv = list(g), list(h), list(a), list(b)
         ok = True
@@ -230,8 +230,9 @@ def _ipa_worker(rank, world, port, variant, q):
 
 
 def test_two_rank_gloo_sharded_ipa():
-    """ShardedIpa's exchange (one all_gather per round, the switch to the replicated tail) over a real
-    two-rank group; sessions, point sums and field sums are the Python oracle's here"""
+    """ShardedIpa's exchange (one all_gather of host packets per round, the switch to the replicated tail)
+    over a real two-rank group; the sessions are the Python oracle's, the sums of the ranks' shares the
+    library's host sums (bph_points_sum, bph_scalars_sum)"""
     for variant in (0, 1):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
@@ -290,3 +291,35 @@ def test_fold_todos_witness_by_residue_class():
             for rank in range(world):
                 got = fold_todos_witness_shard(ctx, c.id, CH, CHI, W, rank, world)
                 assert oo.unpack_field(got, c.n) == full[rank::world], (c.name, world, rank)
+
+
+def test_host_sums_of_rank_shares():
+    """bph_points_sum / bph_scalars_sum (the combination of a sharded round's shares on the host) against
+    the Python oracle: sums with the identity, of a point and its negative, of equal points"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bp_oracle as oo
+    from bulletproofs_amd.host_mirror import points_sum, scalars_sum
+
+    for c in (oo.SECP256K1, oo.VESTA):
+        rng = oo.SplitMix64(0x5A3 + c.id)
+        one = oo.pack_field([1], c.p)[0]
+
+        def xyz(P):
+            out = np.zeros(12, dtype=np.uint64)
+            if P is None:
+                out[0:4], out[4:8] = one, one
+            else:
+                out[0:4], out[4:8], out[8:12] = oo.pack_field([P[0]], c.p)[0], oo.pack_field([P[1]], c.p)[0], one
+            return out
+
+        pts = [oo.scalar_mul(rng.field(c.n), c.g, c) for _ in range(5)]
+        neg = (pts[0][0], (c.p - pts[0][1]) % c.p)
+        cases = [pts, [pts[0], None, pts[1]], [pts[0], neg], [pts[2], pts[2]], [None, None], [pts[3]], []]
+        for case in cases:
+            want = None
+            for P in case:
+                want = oo.add(want, P, c)
+            got = points_sum(c.id, np.stack([xyz(P) for P in case]) if case else np.zeros((0, 12), dtype=np.uint64))
+            assert np.array_equal(got, xyz(want)), (c.name, case)
+        vals = [rng.field(c.n) for _ in range(7)] + [c.n - 1, c.n - 1]
+        assert oo.unpack_field(scalars_sum(c.id, oo.pack_field(vals, c.n)).reshape(1, 4), c.n)[0] == sum(vals) % c.n
