@@ -63,9 +63,9 @@ def make_inputs(n, rank):
     return ks
 
 
-def gen_points_on_gpu(ctx, n, rank):
-    """n distinct valid points: (rank*n + i + 1) * G computed by the library's own
-    per-point scaling kernel from the generator (setup, untimed)."""
+def gen_points_on_gpu(ctx, n, rank, stride=1, first=None):
+    """n distinct valid points: (first + stride * i) * G for i < n (first = rank * n + 1 unless given) computed by
+    the library's own per-point scaling kernel from the generator (setup, untimed)."""
     # secp256k1 generator in Montgomery form
     p = (1 << 256) - (1 << 32) - 977
     gx = 0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798
@@ -79,10 +79,10 @@ def gen_points_on_gpu(ctx, n, rank):
     X = np.tile(np.array(limbs(gx * r % p), dtype=np.uint64), (n, 1))
     Y = np.tile(np.array(limbs(gy * r % p), dtype=np.uint64), (n, 1))
     # scalars rank*n + i + 1 in Montgomery form: (v * R) mod order, vectorised via Python ints per chunk
-    base = rank * n + 1
+    base = rank * n + 1 if first is None else first
     rm = r % order
     S = np.zeros((n, 4), dtype=np.uint64)
-    vals = [((base + i) * rm) % order for i in range(n)]
+    vals = [((base + stride * i) * rm) % order for i in range(n)]
     for k in range(4):
         S[:, k] = np.array([(v >> (64 * k)) & ((1 << 64) - 1) for v in vals], dtype=np.uint64)
     ox, oy, oi = ctx.scale_points(0, (X, Y, None), S)
@@ -343,7 +343,7 @@ def cpu_range_baseline(gs, hs, ugh, values, gamma, n_bits, seed, samples):
                        f"(oracle/bp_oracle_proto.c, OpenMP inside the MSMs and folds); not the arkworks binary")
 
 
-def range_proofs(ctx, device, workers=8, per_worker=8, cpu=True):
+def range_proofs(ctx, device, workers=8, per_worker=8, cpu=True, extras=True):
     """second half of the metric: aggregated range proof, 64 values x 64 bits
     (benches/aggregate_range_bench.rs:93-97), proved and verified through the GPU path by the
     host mirror with the seeded transcript stand-in; measured outside the timed MSM steps.  Beside
@@ -360,6 +360,10 @@ def range_proofs(ctx, device, workers=8, per_worker=8, cpu=True):
                                                  per_worker, seed, seed + 1)
     if not (one["ok"] and thr["ok"]):
         raise SystemExit("aggregated range proof failed to verify")
+    if not extras:  # the figures that are summed over the GPUs of a node
+        return {"workload": "m = 64 values x 64 bits (N = 4096), secp256k1, prove and verify, 1 GPU", "prove_per_s": thr["prove_per_s"],
+                "verify_per_s": thr["verify_per_s"], "host_threads": workers,
+                "one_at_a_time": {"prove_ms": one["prove_ms"], "verify_ms": one["verify_ms"]}}
     g1, h1 = tuple(None if v is None else v[:64] for v in gs), tuple(None if v is None else v[:64] for v in hs)
     host_mirror.range_aggregate_roundtrip(ctx, bp.SECP256K1, g1, h1, ugh, values[:1], gamma[:1], 64, seed, seed + 1, reps=1,
                                           single=True)
@@ -396,6 +400,94 @@ def range_proofs(ctx, device, workers=8, per_worker=8, cpu=True):
     if cpu:
         out["cpu_baseline"] = cpu_range_baseline(gs, hs, ugh, values, gamma, 64, seed, 3)
         out["single_value_64_bit"]["cpu_baseline"] = cpu_range_baseline(g1, h1, ugh, values[:1], gamma[:1], 64, seed, 5)
+    return out
+
+
+def distributed_legs(ctx, bp, torch, dist, rank, world, local_rank, sharded_cls, args):
+    """What the configurations quoted on several GPUs look like over `world` ranks, beside the weak-scaling MSM:
+    a 2^20-point MSM cut over the ranks (strong scaling); aggregated range proofs as independent proofs per GPU
+    (the scaling that applies to them) and, as the number SURVEY's "expect < 1x" stands for, the 8192-point
+    commitment MSM of one proof cut over the ranks; the degree-2^20 - 1 polynomial-commitment flow with its
+    vectors spread over the ranks by residue class (bp_host_sharded.hpp).  Every rank takes part; rank 0 reports."""
+    from bulletproofs_amd import host_mirror
+    from bulletproofs_amd.sharded import host_gather, shard_range
+
+    out = {}
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()  # noqa: E731
+
+    def timed_sharded_msm(n_total, steps):
+        b, e = shard_range(n_total, rank, world)
+        n = e - b
+        px, py = gen_points_on_gpu(ctx, max(n, 1), rank)
+        ks = make_inputs(max(n, 1), rank)
+        dx, dy, dk = to_dev(px), to_dev(py), to_dev(ks)
+        sm = sharded_cls(ctx, bp.SECP256K1, dist=dist, n_total=n_total)
+        for _ in range(3):
+            sm.msm(dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sm.msm(dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / steps * 1e3, sm.window_bits()
+
+    # (1) strong scaling of the headline size
+    ms, cb = timed_sharded_msm(1 << LOG2_N, args.steps)
+    out["msm_strong_2_20"] = {"workload": f"one secp256k1 MSM of 2^{LOG2_N} points cut over {world} GPU(s) by point range, window sums "
+                                          f"all-gathered over RCCL, combined on every GPU", "ms_per_step": ms,
+                              "points_per_s": (1 << LOG2_N) / ms * 1e3, "window_bits": cb, "steps": args.steps}
+    # (2) the commitment MSM of one 64 x 64-bit range proof (2 x 4096 points) cut the same way
+    ms, cb = timed_sharded_msm(8192, 50)
+    out["range_commitment_msm_8192_sharded"] = {"workload": f"one MSM of 8192 points (the A or S commitment of a 64 x 64-bit range proof, "
+                                                            f"src/range/aggregate.rs:80-83) cut over {world} GPU(s)", "ms_per_msm": ms,
+                                                "window_bits": cb,
+                                                "note": "a chain of short launches per rank plus one collective: cutting it does not "
+                                                        "shorten it; range proofs scale as independent proofs per GPU (range_proofs)"}
+    # (3) aggregated range proofs: every GPU proves and verifies its own proofs
+    if not args.no_range:
+        mine = range_proofs(ctx, local_rank, cpu=False, extras=False)
+        t = torch.tensor([mine["prove_per_s"], mine["verify_per_s"]], dtype=torch.float64, device="cuda")
+        per_gpu = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(per_gpu, t)
+        out["range_proofs"] = {"metric": "aggregated 64-bit range proofs/sec", "workload": mine["workload"].replace("1 GPU", f"{world} GPU(s), "
+                               "independent proofs on every GPU"),
+                               "prove_per_s": float(sum(v[0].item() for v in per_gpu)), "verify_per_s": float(sum(v[1].item() for v in per_gpu)),
+                               "per_gpu_prove_per_s": [float(v[0].item()) for v in per_gpu],
+                               "per_gpu_verify_per_s": [float(v[1].item()) for v in per_gpu], "host_threads_per_gpu": mine["host_threads"],
+                               "one_at_a_time": mine["one_at_a_time"]}
+    # (4) polynomial commitment of degree 2^20 - 1 over the ranks: rank r holds generators and coefficients r, r + world, ...
+    if not args.no_range and world & (world - 1) == 0:
+        n = 1 << 20
+        nl = n // world
+        px, py = gen_points_on_gpu(ctx, nl, rank, stride=world, first=rank + 1)
+        hx, hy = gen_points_on_gpu(ctx, 2, 0, first=n + 1)
+        hg = np.stack([np.concatenate([hx[0], hy[0]]), np.concatenate([hx[1], hy[1]])])
+        rng = np.random.default_rng(SEED + 55)  # the same whole vectors on every rank, each keeps its slice
+        coeffs = rng.integers(0, 1 << 64, (n, 4), dtype=np.uint64)
+        coeffs[:, 3] &= np.uint64((1 << 63) - 1)
+        rx = rng.integers(0, 1 << 64, (2, 4), dtype=np.uint64)
+        rx[:, 3] &= np.uint64((1 << 63) - 1)
+        sl = slice(rank, None, world)
+        c1, c2 = np.ascontiguousarray(coeffs[sl]), np.ascontiguousarray(coeffs[::-1][sl])
+        group = dist.new_group(backend="gloo") if world > 1 else None  # host packets: 24 u64 per rank and round
+        gather = host_gather(dist, group) if world > 1 else None
+        host_mirror.sharded_poly_roundtrip(ctx, bp.SECP256K1, (px, py, None), hg, c1, None, n, rx[0], rx[1], rank, world, gather,
+                                           SEED, SEED + 1)  # warm-up
+        res = host_mirror.sharded_poly_roundtrip(ctx, bp.SECP256K1, (px, py, None), hg, c1, c2, n, rx[0], rx[1], rank, world, gather,
+                                                 SEED, SEED + 1)
+        if not (res["verify_ok"] and res["lazy_ok"] and res["halo_ok"]):
+            raise SystemExit("sharded polynomial-commitment opening failed to verify")
+        t = torch.tensor([res["prove_ms"], res["verify_ms"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["poly_commit_2_20_sharded"] = {"workload": f"polynomial commitment opening, degree 2^20 - 1, vectors spread over {world} GPU(s) by "
+                                                       f"residue class of the index, CRS slices resident; with the second opening and the fold "
+                                                       f"of the two deferred checks verified", "prove_ms": float(t[0].item()),
+                                           "verify_ms": float(t[1].item()), "all_verified": True,
+                                           "exchange": "24 u64 per rank and round between host buffers (gloo all_gather)"}
     return out
 
 
@@ -441,6 +533,7 @@ def main():
     ap.add_argument("--no-range", action="store_true", help="skip the aggregated range proof figures")
     ap.add_argument("--no-in-flight", action="store_true", help="skip the two-MSMs-in-flight figure")
     ap.add_argument("--no-streaming", action="store_true", help="skip the fold / dot / s-vector bandwidth figures")
+    ap.add_argument("--no-dist-legs", action="store_true", help="N > 1: only the headline MSM, none of the other multi-GPU legs")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 2^log2n points on every GPU; strong: 2^log2n points in total, split by shard_range")
     args = ap.parse_args()
@@ -459,7 +552,13 @@ def main():
     torch.cuda.set_device(local_rank)
     # BP_BENCH_FORCE_DIST=1 runs the collective path even with one rank (rehearsal on a 1-GPU box)
     use_dist = world > 1 or os.environ.get("BP_BENCH_FORCE_DIST") == "1"
+    saved_stdout = None
     if use_dist:
+        # RCCL prints a version banner on stdout when its first communicator comes up: while the collectives
+        # run, file descriptor 1 points at stderr, so that the JSON line is the only thing on stdout
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -504,6 +603,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the legs every rank takes part in (collectives inside): strong-scaling MSM, range proofs per GPU, sharded polynomial commitment
+    legs = None
+    if use_dist and args.scaling == "weak" and args.log2n == LOG2_N and not args.no_dist_legs:
+        legs = distributed_legs(ctx, bp, torch, dist, rank, world, local_rank, ShardedMsm, args)
     if rank == 0:
         # plan facts: window width and count chosen by the library for this n
         if use_dist:
@@ -579,9 +682,14 @@ def main():
             out["msm_two_in_flight"] = msm_in_flight(bp, local_rank, dx, dy, dk, n, args.steps)
         if world == 1 and not args.no_streaming:
             out["streaming"] = streaming_kernels(ctx, torch)
+        if legs is not None:
+            out["distributed"] = legs
         if world == 1 and not args.no_range:
             out["other_configs"] = other_configs(ctx, px, py, cpu=not args.no_cpu_baseline)
         assert res is not None
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
