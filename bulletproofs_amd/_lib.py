@@ -126,6 +126,18 @@ SIGNATURES = {
     "bp_ipa_set_u_resident": (ci, [vp, sz, vp]),
     "bp_ipa_read": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "bp_ipa_free": (None, [vp]),
+    "bp_range_batch_begin": (ci, [vp, vp, sz, sz, C.c_uint, C.POINTER(vp)]),
+    "bp_range_batch_free": (None, [vp]),
+    "bp_range_batch_size": (sz, [vp]),
+    "bp_range_batch_commit": (ci, [vp, vp, vp, vp, C.c_uint, vp, vp, vp]),
+    "bp_range_batch_poly": (ci, [vp, vp, vp, vp, vp]),
+    "bp_range_batch_tcommit": (ci, [vp, vp, vp]),
+    "bp_range_batch_eval": (ci, [vp, vp, vp]),
+    "bp_range_batch_ipa_begin": (ci, [vp, vp]),
+    "bp_range_batch_ipa_len": (sz, [vp]),
+    "bp_range_batch_round_lr": (ci, [vp, vp]),
+    "bp_range_batch_round_fold": (ci, [vp, vp, vp]),
+    "bp_range_batch_finish": (ci, [vp, vp]),
     "bp_bench_int_mad_peak": (ci, [vp, ci, C.POINTER(C.c_double)]),
     "bp_microbench": (ci, [vp, ci, ci, ci, C.POINTER(C.c_float)]),
     "bp_last_kernel_ms": (ci, [vp, ci, C.POINTER(C.c_float)]),

@@ -344,9 +344,9 @@ void finish_windows(int curve, const uint64_t* win, int n_windows, int c, uint64
 // room for `host_extra` more bytes is kept behind them)
 int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, MsmPlan* plan,
                u32** d_windows, int groups = 1, const MsmExtra* extra = nullptr, const MsmTable* table = nullptr,
-               bool win_host = false, size_t host_extra = 0) {
+               bool win_host = false, size_t host_extra = 0, int batch = 1) {
   size_t n = p0.n + p1.n + (extra ? 2 : 0);
-  hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan, table ? table->stride : 0, true);
+  hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan, table ? table->stride : 0, true, batch);
   if (e != hipSuccess) return fail(ctx, BP_E_ARG, "msm plan (n too large?)", e);
   MsmWorkspace ws{};
   void* p;
@@ -2207,6 +2207,353 @@ int bp_ipa_read(bp_ipa* s, uint64_t* gx, uint64_t* gy, uint8_t* ginf, uint64_t* 
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return BP_OK;
 }
+
+}  // extern "C"
+
+// ---- batches of aggregated range proofs ---------------------------------------------------------
+
+struct bp_range_batch {
+  bp_ctx* ctx = nullptr;
+  const bp_bases* bases = nullptr;
+  int curve = 0, batch = 0;
+  size_t m = 0, n = 0;
+  unsigned n_bits = 0;
+  RangeBatchTabs tl{};
+  void* block = nullptr;   // one device allocation behind every pointer below
+  char* host = nullptr;    // pinned: results the last launch of a phase writes itself
+  uint64_t* values = nullptr;                   // [B][m]
+  uint64_t* seeds = nullptr;                    // [B]
+  u32 *s_lr = nullptr, *sa = nullptr;           // [B][2n]: s_L || s_R, a_L || a_R
+  u32 *l0 = nullptr, *r0 = nullptr, *r1 = nullptr;                   // [B][n]
+  u32 *a = nullptr, *b = nullptr, *a2 = nullptr, *b2 = nullptr;      // [B][n]: the arguments' vectors and the other side of the fold
+  u32 *cg = nullptr, *ch = nullptr, *eg = nullptr, *eh = nullptr;    // [B][n]
+  u32 *tabs = nullptr, *pow2 = nullptr;         // [B][tl.row], [n_bits]
+  u32 *yz = nullptr;                            // [3][B]: y, y^-1, z
+  u32 *sc0 = nullptr, *sc1 = nullptr;           // [B]: one scalar per proof (alpha / x / challenge, rho / factor / inverse)
+  u32 *factors = nullptr;                       // [B]: the factor of u
+  u32 *tsc = nullptr;                           // [B][4]: t1, tao1, t2, tao2
+  u32 *dots = nullptr;                          // [B][4]
+  u32 *partials = nullptr;                      // [B][3 * ceil(n / 256)]
+  u32* flag = nullptr;                          // one word
+  size_t cur_n = 0;
+  bool prepped = false, has_poly = false, in_ipa = false;
+};
+
+namespace {
+
+// affine (Z = 1) forms of `count` XYZZ sums (boundary form, 16 u64 each) with one shared inversion
+template <class Fq>
+void normalize_xyzz_batch(const uint64_t* xyzz, size_t count, uint64_t* out_xyz) {
+  using namespace host;
+  std::vector<HFe> pre(count);
+  HFe run = h_one<Fq>();
+  const HFe one = h_one<Fq>();
+  for (size_t i = 0; i < count; i++) {
+    HFe zzz;
+    memcpy(zzz.v, xyzz + 16 * i + 12, 32);
+    pre[i] = run;
+    if (!h_is_zero(zzz)) run = h_mul<Fq>(run, zzz);
+  }
+  HFe inv = h_inv_kaliski<Fq>(run);
+  for (size_t i = count; i-- > 0;) {
+    HFe x, y, zz, zzz;
+    memcpy(x.v, xyzz + 16 * i, 32); memcpy(y.v, xyzz + 16 * i + 4, 32);
+    memcpy(zz.v, xyzz + 16 * i + 8, 32); memcpy(zzz.v, xyzz + 16 * i + 12, 32);
+    uint64_t* o = out_xyz + 12 * i;
+    if (h_is_zero(zzz)) {  // the identity: (1, 1, 0)
+      memcpy(o, one.v, 32); memcpy(o + 4, one.v, 32); memset(o + 8, 0, 32);
+      continue;
+    }
+    const HFe i3 = h_mul<Fq>(inv, pre[i]);  // 1 / zzz
+    inv = h_mul<Fq>(inv, zzz);
+    const HFe t = h_mul<Fq>(zz, i3);        // 1 / zz = (zz / zzz)^2
+    const HFe ax = h_mul<Fq>(x, h_sqr<Fq>(t)), ay = h_mul<Fq>(y, i3);
+    memcpy(o, ax.v, 32); memcpy(o + 4, ay.v, 32); memcpy(o + 8, one.v, 32);
+  }
+}
+
+// the window sums of a batched two-group table plan added per (proof, group) on the device into the batch's
+// pinned buffer, then normalised on the host: out[b][g] (12 u64 each)
+int rangeb_collect(bp_range_batch* rb, const MsmPlan& plan, const u32* d_win, uint64_t* out) {
+  bp_ctx* ctx = rb->ctx;
+  const int sums = rb->batch * 2;
+  hipError_t e = launch_window_group_sums(rb->curve, d_win, plan.group_windows, sums, (u32*)rb->host, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "window_group_sums", e);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (rb->curve == BP_SECP256K1)
+    normalize_xyzz_batch<Secp256k1Fq>((const uint64_t*)rb->host, (size_t)sums, out);
+  else
+    normalize_xyzz_batch<VestaFq>((const uint64_t*)rb->host, (size_t)sums, out);
+  return BP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void bp_range_batch_free(bp_range_batch* rb) {
+  if (!rb) return;
+  Guard g(rb->ctx);
+  (void)hipStreamSynchronize(rb->ctx->stream);
+  if (rb->block) (void)hipFree(rb->block);
+  if (rb->host) (void)hipHostFree(rb->host);
+  delete rb;
+}
+
+int bp_range_batch_begin(bp_ctx* ctx, const bp_bases* bases, size_t batch, size_t m, unsigned n_bits, bp_range_batch** out) {
+  if (!ctx || !bases || !out) return fail(ctx, BP_E_ARG, "bp_range_batch_begin: null argument");
+  if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_range_batch_begin: bases belong to another context");
+  const size_t n = m * (size_t)n_bits;
+  if (batch < 1 || batch > (size_t)kMsmMaxBatch || m == 0 || n_bits == 0 || n_bits > 64 || n < 2 || (n & (n - 1)) || n > 4096)
+    return fail(ctx, BP_E_ARG, "bp_range_batch_begin: 1 <= batch <= 64, m * n_bits a power of two in 2..4096");
+  if (bases->n < 2 * n + 3) return fail(ctx, BP_E_ARG, "bp_range_batch_begin: base set shorter than gs | hs | u | g | h (2 m n_bits + 3)");
+  if (!bases->tab) return fail(ctx, BP_E_STATE, "bp_range_batch_begin: the base set has no window tables (bp_bases_precompute)");
+  Guard g(ctx);
+  bp_range_batch* rb = new (std::nothrow) bp_range_batch();
+  if (!rb) return fail(ctx, BP_E_OOM, "host allocation");
+  rb->ctx = ctx; rb->bases = bases; rb->curve = bases->curve; rb->batch = (int)batch; rb->m = m; rb->n = n; rb->n_bits = n_bits;
+  // powers of y by two tables of about sqrt(n) entries
+  u32 lo = 1;
+  while ((size_t)lo * lo < n) lo <<= 1;
+  const u32 hi = (u32)((n + lo - 1) / lo);
+  RangeBatchTabs& tl = rb->tl;
+  tl.lo = lo; tl.hi = hi;
+  tl.zpow = 0; tl.ylo = (u32)m; tl.yhi = tl.ylo + lo; tl.yilo = tl.yhi + hi; tl.yihi = tl.yilo + lo; tl.row = tl.yihi + hi;
+  const size_t B = batch, blocks = (n + 255) / 256;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+  const size_t o_values = take(B * m * 8), o_seeds = take(B * 8), o_slr = take(B * 2 * n * 32), o_sa = take(B * 2 * n * 32);
+  const size_t o_l0 = take(B * n * 32), o_r0 = take(B * n * 32), o_r1 = take(B * n * 32);
+  const size_t o_a = take(B * n * 32), o_b = take(B * n * 32), o_a2 = take(B * n * 32), o_b2 = take(B * n * 32);
+  const size_t o_cg = take(B * n * 32), o_ch = take(B * n * 32), o_eg = take(B * n * 32), o_eh = take(B * n * 32);
+  const size_t o_tabs = take(B * tl.row * 32), o_pow2 = take((size_t)n_bits * 32), o_yz = take(B * 96);
+  const size_t o_sc0 = take(B * 32), o_sc1 = take(B * 32), o_fac = take(B * 32), o_tsc = take(B * 128), o_dots = take(B * 128);
+  const size_t o_part = take(B * 3 * blocks * 32), o_flag = take(256);
+  hipError_t e = hipMalloc(&rb->block, off);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&rb->host, B * 2 * 128 + B * 64, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    if (rb->block) (void)hipFree(rb->block);
+    delete rb;
+    return fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "bp_range_batch_begin", e);
+  }
+  char* base = (char*)rb->block;
+  auto at = [&](size_t o) { return (u32*)(base + o); };
+  rb->values = (uint64_t*)(base + o_values); rb->seeds = (uint64_t*)(base + o_seeds);
+  rb->s_lr = at(o_slr); rb->sa = at(o_sa); rb->l0 = at(o_l0); rb->r0 = at(o_r0); rb->r1 = at(o_r1);
+  rb->a = at(o_a); rb->b = at(o_b); rb->a2 = at(o_a2); rb->b2 = at(o_b2);
+  rb->cg = at(o_cg); rb->ch = at(o_ch); rb->eg = at(o_eg); rb->eh = at(o_eh);
+  rb->tabs = at(o_tabs); rb->pow2 = at(o_pow2); rb->yz = at(o_yz); rb->sc0 = at(o_sc0); rb->sc1 = at(o_sc1);
+  rb->factors = at(o_fac); rb->tsc = at(o_tsc); rb->dots = at(o_dots); rb->partials = at(o_part); rb->flag = at(o_flag);
+  // 2^i, i < n_bits
+  std::vector<uint64_t> p2(4 * (size_t)n_bits);
+  {
+    host::HFe v = rb->curve == BP_SECP256K1 ? host::h_one<Secp256k1Fr>() : host::h_one<VestaFr>();
+    for (unsigned i = 0; i < n_bits; i++) {
+      memcpy(&p2[4 * i], v.v, 32);
+      v = rb->curve == BP_SECP256K1 ? host::h_dbl<Secp256k1Fr>(v) : host::h_dbl<VestaFr>(v);
+    }
+  }
+  int rc = stage_h2d(ctx, rb->pow2, p2.data(), p2.size() * 8);
+  if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, BP_E_HIP, "bp_range_batch_begin: sync");
+  if (rc != BP_OK) {
+    (void)hipFree(rb->block);
+    (void)hipHostFree(rb->host);
+    delete rb;
+    return rc;
+  }
+  *out = rb;
+  return BP_OK;
+}
+
+size_t bp_range_batch_size(const bp_range_batch* rb) { return rb ? (size_t)rb->batch : 0; }
+
+int bp_range_batch_commit(bp_range_batch* rb, const uint64_t* values, const uint64_t* s_lr, const uint64_t* seeds,
+                          unsigned first_draw, const uint64_t* alpha, const uint64_t* rho, uint64_t* out_as_xyz) {
+  if (!rb || !values || (!s_lr && !seeds) || !alpha || !rho || !out_as_xyz) return BP_E_ARG;
+  bp_ctx* ctx = rb->ctx;
+  Guard g(ctx);
+  const size_t B = (size_t)rb->batch, n = rb->n;
+  rb->has_poly = rb->in_ipa = false;
+  CHK(stage_h2d(ctx, rb->values, values, B * rb->m * 8));
+  CHK(stage_h2d(ctx, rb->sc0, alpha, B * 32));
+  CHK(stage_h2d(ctx, rb->sc1, rho, B * 32));
+  hipError_t e;
+  if (s_lr) {
+    HIPCHK(ctx, hipMemcpyAsync(rb->s_lr, s_lr, B * 2 * n * 32, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    CHK(stage_h2d(ctx, rb->seeds, seeds, B * 8));
+    HIPCHK(ctx, hipMemsetAsync(rb->flag, 0, 4, ctx->stream));
+    e = launch_rangeb_blinders(rb->curve, rb->seeds, first_draw, (u32)(2 * n), rb->batch, rb->s_lr, rb->flag, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "rangeb_blinders", e);
+  }
+  e = launch_rangeb_commit_scalars(rb->curve, rb->values, (u32)rb->m, rb->n_bits, (u32)n, rb->batch, rb->sa, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "rangeb_commit_scalars", e);
+  // A_b = <a_L || a_R, gs || hs> + alpha_b h, S_b = <s_L || s_R, gs || hs> + rho_b h (src/range/aggregate.rs:80-83) as
+  // groups 0 and 1 of every proof's pass over the same 2n points; h rides along as each group's extra point
+  const bp_bases* bs = rb->bases;
+  MsmPart p0{bs->x, bs->y, bs->inf, rb->sa, 2 * n};
+  MsmPart p1{bs->x, bs->y, bs->inf, rb->s_lr, 2 * n};
+  p1.group_lo = p1.group_hi = 1;
+  p0.batch_stride = p1.batch_stride = 2 * n * 8;
+  MsmExtra extra{{bs->x, bs->x}, {rb->sc0, rb->sc1}};
+  extra.tab_index[0] = extra.tab_index[1] = 2 * n + 2;
+  extra.batch_stride[0] = extra.batch_stride[1] = 8;
+  MsmTable table{bs->tab, bs->n};
+  MsmPlan plan;
+  u32* d_win = nullptr;
+  CHK(msm_device(ctx, rb->curve, p0, p1, &plan, &d_win, 2, &extra, &table, false, 0, rb->batch));
+  CHK(rangeb_collect(rb, plan, d_win, out_as_xyz));
+  if (!s_lr) {
+    uint32_t rej = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&rej, rb->flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (rej) return fail(ctx, BP_E_STATE, "bp_range_batch_commit: a generated blinder was not below the modulus; pass the blinders instead");
+  }
+  return BP_OK;
+}
+
+int bp_range_batch_poly(bp_range_batch* rb, const uint64_t* y, const uint64_t* y_inv, const uint64_t* z, uint64_t* out_t1t2) {
+  if (!rb || !y || !y_inv || !z || !out_t1t2) return BP_E_ARG;
+  bp_ctx* ctx = rb->ctx;
+  Guard g(ctx);
+  const size_t B = (size_t)rb->batch;
+  CHK(stage_h2d(ctx, rb->yz, y, B * 32));
+  CHK(stage_h2d(ctx, rb->yz + B * 8, y_inv, B * 32));
+  CHK(stage_h2d(ctx, rb->yz + 2 * B * 8, z, B * 32));
+  hipError_t e = launch_rangeb_tables(rb->curve, rb->yz, rb->tl, (u32)rb->m, rb->batch, rb->tabs, ctx->stream);
+  if (e == hipSuccess)
+    e = launch_rangeb_poly(rb->curve, rb->values, (u32)rb->m, rb->n_bits, (u32)rb->n, rb->batch, rb->tabs, rb->tl, rb->pow2, rb->s_lr,
+                           rb->yz + 2 * B * 8, rb->l0, rb->r0, rb->r1, rb->partials, (u32*)rb->host, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "rangeb_poly", e);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out_t1t2, rb->host, B * 64);
+  rb->has_poly = true;
+  return BP_OK;
+}
+
+int bp_range_batch_tcommit(bp_range_batch* rb, const uint64_t* t_scalars, uint64_t* out_tt_xyz) {
+  if (!rb || !t_scalars || !out_tt_xyz) return BP_E_ARG;
+  bp_ctx* ctx = rb->ctx;
+  Guard g(ctx);
+  const size_t B = (size_t)rb->batch, n = rb->n;
+  CHK(stage_h2d(ctx, rb->tsc, t_scalars, B * 128));
+  // T1_b = t1 g + tao1 h, T2_b = t2 g + tao2 h (src/range/aggregate.rs:126-127): two points per group
+  const bp_bases* bs = rb->bases;
+  const size_t gi = 2 * n + 1;
+  MsmPart p0{bs->x + gi * 8, bs->y + gi * 8, bs->inf + gi, rb->tsc, 2};
+  MsmPart p1{bs->x + gi * 8, bs->y + gi * 8, bs->inf + gi, rb->tsc + 16, 2};
+  p1.group_lo = p1.group_hi = 1;
+  p0.tab_offset = p1.tab_offset = gi;
+  p0.batch_stride = p1.batch_stride = 32;
+  MsmTable table{bs->tab, bs->n};
+  MsmPlan plan;
+  u32* d_win = nullptr;
+  CHK(msm_device(ctx, rb->curve, p0, p1, &plan, &d_win, 2, nullptr, &table, false, 0, rb->batch));
+  return rangeb_collect(rb, plan, d_win, out_tt_xyz);
+}
+
+int bp_range_batch_eval(bp_range_batch* rb, const uint64_t* x, uint64_t* out_t_hat) {
+  if (!rb || !x || !out_t_hat) return BP_E_ARG;
+  bp_ctx* ctx = rb->ctx;
+  Guard g(ctx);
+  if (!rb->has_poly) return fail(ctx, BP_E_STATE, "bp_range_batch_eval: no vector polynomials (call bp_range_batch_poly first)");
+  const size_t B = (size_t)rb->batch;
+  CHK(stage_h2d(ctx, rb->sc0, x, B * 32));
+  hipError_t e = launch_rangeb_eval(rb->curve, rb->l0, rb->s_lr, rb->r0, rb->r1, (u32)rb->n, rb->batch, rb->sc0, rb->a, rb->b,
+                                    rb->partials, (u32*)rb->host, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "rangeb_eval", e);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out_t_hat, rb->host, B * 32);
+  return BP_OK;
+}
+
+int bp_range_batch_ipa_begin(bp_range_batch* rb, const uint64_t* u_factor) {
+  if (!rb || !u_factor) return BP_E_ARG;
+  bp_ctx* ctx = rb->ctx;
+  Guard g(ctx);
+  if (!rb->has_poly) return fail(ctx, BP_E_STATE, "bp_range_batch_ipa_begin: no evaluated vectors (bp_range_batch_poly, _eval first)");
+  CHK(stage_h2d(ctx, rb->factors, u_factor, (size_t)rb->batch * 32));
+  hipError_t e = launch_ipab_init(rb->curve, rb->tabs, rb->tl, (u32)rb->n, rb->batch, rb->cg, rb->ch, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipab_init", e);
+  rb->cur_n = rb->n;
+  rb->prepped = false;
+  rb->in_ipa = true;
+  return BP_OK;
+}
+
+size_t bp_range_batch_ipa_len(const bp_range_batch* rb) { return rb && rb->in_ipa ? rb->cur_n : 0; }
+
+int bp_range_batch_round_lr(bp_range_batch* rb, uint64_t* out_lr_xyz) {
+  if (!rb || !out_lr_xyz) return BP_E_ARG;
+  bp_ctx* ctx = rb->ctx;
+  Guard g(ctx);
+  if (!rb->in_ipa || rb->cur_n < 2) return fail(ctx, BP_E_STATE, "bp_range_batch_round_lr: no round left");
+  const size_t n = rb->n, h = rb->cur_n / 2;
+  hipError_t e;
+  if (!rb->prepped) {
+    e = launch_ipab_round_prep(rb->curve, rb->a, rb->b, rb->cg, rb->ch, (u32)n, (u32)h, rb->batch, rb->factors, rb->eg, rb->eh,
+                               rb->dots, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipab_round_prep", e);
+  }
+  rb->prepped = false;
+  // L: G_hi with a_lo, H_lo with b_hi; R: G_lo with a_hi, H_hi with b_lo; u' = factor * u with factor c_l, factor c_r
+  // (src/ipa/mod.rs:43-71) -- bp_ipa_round_lr's pass for every proof of the batch at once
+  const bp_bases* bs = rb->bases;
+  MsmPart pg{bs->x, bs->y, bs->inf, rb->eg, n};
+  pg.sel_half = h; pg.group_hi = 0; pg.group_lo = 1;
+  MsmPart ph{bs->x + n * 8, bs->y + n * 8, bs->inf + n, rb->eh, n};
+  ph.sel_half = h; ph.group_lo = 0; ph.group_hi = 1;
+  ph.tab_offset = n;
+  pg.batch_stride = ph.batch_stride = n * 8;
+  MsmExtra extra{{bs->x, bs->x}, {rb->dots + 16, rb->dots + 24}};
+  extra.tab_index[0] = extra.tab_index[1] = 2 * n;
+  extra.batch_stride[0] = extra.batch_stride[1] = 32;
+  MsmTable table{bs->tab, bs->n};
+  MsmPlan plan;
+  u32* d_win = nullptr;
+  CHK(msm_device(ctx, rb->curve, pg, ph, &plan, &d_win, 2, &extra, &table, false, 0, rb->batch));
+  return rangeb_collect(rb, plan, d_win, out_lr_xyz);
+}
+
+int bp_range_batch_round_fold(bp_range_batch* rb, const uint64_t* x, const uint64_t* x_inv) {
+  if (!rb || !x || !x_inv) return BP_E_ARG;
+  bp_ctx* ctx = rb->ctx;
+  Guard g(ctx);
+  if (!rb->in_ipa || rb->cur_n < 2) return fail(ctx, BP_E_STATE, "bp_range_batch_round_fold: no round left");
+  const size_t B = (size_t)rb->batch, h = rb->cur_n / 2;
+  CHK(stage_h2d(ctx, rb->sc0, x, B * 32));
+  CHK(stage_h2d(ctx, rb->sc1, x_inv, B * 32));
+  hipError_t e;
+  if (h >= 2) {
+    e = launch_ipab_fold_prep(rb->curve, rb->a, rb->b, rb->a2, rb->b2, rb->cg, rb->ch, (u32)rb->n, (u32)h, rb->batch, rb->sc0, rb->sc1,
+                              rb->factors, rb->eg, rb->eh, rb->dots, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipab_fold_prep", e);
+    std::swap(rb->a, rb->a2);
+    std::swap(rb->b, rb->b2);
+    rb->prepped = true;
+  } else {
+    // two elements to one: the proofs' final a, b go to the pinned buffer
+    e = launch_ipab_last_fold(rb->curve, rb->a, rb->b, (u32)rb->n, rb->batch, rb->sc0, rb->sc1, (u32*)rb->host, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipab_last_fold", e);
+  }
+  rb->cur_n = h;
+  return BP_OK;
+}
+
+int bp_range_batch_finish(bp_range_batch* rb, uint64_t* out_ab) {
+  if (!rb || !out_ab) return BP_E_ARG;
+  bp_ctx* ctx = rb->ctx;
+  Guard g(ctx);
+  if (!rb->in_ipa || rb->cur_n != 1) return fail(ctx, BP_E_STATE, "bp_range_batch_finish: rounds left");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out_ab, rb->host, (size_t)rb->batch * 64);
+  rb->in_ipa = false;
+  return BP_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ---- measurement helpers -----------------------------------------------------------
 

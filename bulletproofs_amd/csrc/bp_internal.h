@@ -143,6 +143,9 @@ struct MsmPart {
   size_t sel_half = 0;
   u32 group_lo = 0, group_hi = 0;
   size_t tab_offset = 0;  // table plans: index of this part's first point in the base set
+  // batched plans (MsmPlan::batch > 1): problem b reads its scalars at s + b * batch_stride (u32 units);
+  // the points are the same for every problem of the batch
+  size_t batch_stride = 0;
 };
 
 // Window tables of a registered base set (launch_window_tables): record (w, j) at w*stride + j
@@ -182,6 +185,11 @@ struct MsmPlan {
   int stages;     // > 1: the windows are processed in this many consecutive batches on three streams
   bool two_level; // chunked path: two-level counting sort in place of the key-value radix sort
   bool rowcol;    // bucket reduction by row and column sums of the (n_buckets/256) x 256 bucket matrix
+  // > 1: `batch` independent problems of the same shape over the same points (table plans of the
+  // one-launch front end only): one grid per phase serves them all; n_windows counts the windows of all
+  // problems (problem b owns windows [b * n_windows / batch, (b + 1) * n_windows / batch)), n_total and
+  // entries those of one problem
+  int batch;
 };
 
 // Large single-sum plans run their windows in batches: sorting and the chunk table of batch
@@ -199,7 +207,12 @@ struct MsmPipe {
 int msm_choose_window(size_t n);
 int msm_default_window(size_t n);
 hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride = 0,
-                         bool allow_stages = false);
+                         bool allow_stages = false, int batch = 1);
+constexpr int kMsmMaxBatch = 64;
+// out[q] = sum of the `count` XYZZ points (AoS, 32 words, boundary form) in + (q * count) * 32, q < n_sums: the
+// window sums of a table plan whose windows carry their powers of two already (finish_c == 0), added on the
+// device; out may be host memory the device can write
+hipError_t launch_window_group_sums(int curve, const u32* in, int count, int n_sums, u32* out, hipStream_t st);
 
 struct MsmWorkspace {
   u32* packed;        // points as x|y pairs, 16 u32 each
@@ -232,6 +245,7 @@ struct MsmExtra {
   const u32* xy[2];  // affine x|y, 16 u32, not the identity; extra e goes to group e
   const u32* s[2];   // Montgomery-form scalar, 8 u32
   size_t tab_index[2] = {0, 0};  // table plans: index of the point in the base set
+  size_t batch_stride[2] = {0, 0};  // batched plans: problem b reads extra e's scalar at s[e] + b * batch_stride[e] (u32 units)
 };
 
 // Runs digits -> sort -> bucket accumulation -> bucket reduction; leaves W window

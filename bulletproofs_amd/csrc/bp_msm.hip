@@ -99,10 +99,11 @@ static int key_bits_for(u32 max_key) {
 }
 
 hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride,
-                         bool allow_stages) {
+                         bool allow_stages, int batch) {
   MsmPlan p{};
-  if (groups < 1 || groups > 2) return hipErrorInvalidValue;
+  if (groups < 1 || groups > 2 || batch < 1 || batch > kMsmMaxBatch) return hipErrorInvalidValue;
   p.groups = groups;
+  p.batch = batch;
   p.tab = table_stride != 0 && n_total > 0;
   p.c = (c_override >= 2 && c_override <= 20) ? c_override : msm_choose_window(n_total / groups);
   const bool small_ok = n_total > 0 && n_total <= kSmallMaxPoints && !getenv("BP_MSM_NO_SMALL");
@@ -122,7 +123,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
     // (unless the plan keeps them apart, see tab_virtual)
     if (!p.tab_virtual) p.group_windows = 1;
   }
-  p.n_windows = p.group_windows * groups;
+  p.n_windows = p.group_windows * groups * batch;
   p.n_buckets = 1u << (p.c - 1);
   p.n_total = n_total;
   p.entries = (size_t)p.digit_windows * n_total;
@@ -201,6 +202,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   if ((p.entries >> 21) > p.chunk) p.chunk = (u32)((p.entries >> 21) > 4096 ? 4096 : (p.entries >> 21));
   p.nc_cap = p.entries / p.chunk + nbt + 1 + kMsmMaxStages;  // room for one rounding slot per batch
   p.small = small_ok && p.n_buckets <= kSmallMaxBuckets && (!p.tab || p.tab_virtual);
+  if (batch > 1 && !(p.small && p.tab_virtual)) return hipErrorInvalidValue;
   // narrow windows on more points than one block sorts: the sliced counting sort
   p.mid = (p.tab && !p.tab_virtual) || (!p.small && n_total > 0 && p.n_buckets >= 64 && p.n_buckets <= kMidMaxBuckets &&
                     n_total <= ((size_t)1 << 20) && !getenv("BP_MSM_NO_MID"));
@@ -257,6 +259,8 @@ struct DigitGroups {
   const u32* extra_xy[2];
   const u32* extra_s[2];
   u32 extra_tab[2];  // table plans: index of the extra point in the base set
+  // batched plans: problem b = blockIdx.y reads its scalars b * stride u32 further on
+  u32 s_stride0 = 0, s_stride1 = 0, extra_stride[2] = {0, 0};
 };
 
 template <class C>
@@ -420,7 +424,13 @@ __global__ __launch_bounds__(1024) void k_small_front(
   __shared__ u32 off[kSmallMaxBuckets];
   __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
   __shared__ u32 thr[8], msk[8];  // window w: carry-in threshold T_w and the mask of the low c*w bits
-  const u32 wid = blockIdx.x;
+  // problem blockIdx.y of a batch: its own scalars, its own windows (gwid), the same points
+  const u32 sess = blockIdx.y;
+  s0 += (size_t)sess * sel.s_stride0;
+  s1 += (size_t)sess * sel.s_stride1;
+  sel.extra_s[0] += (size_t)sess * sel.extra_stride[0];
+  sel.extra_s[1] += (size_t)sess * sel.extra_stride[1];
+  const u32 wid = blockIdx.x, gwid = sess * gridDim.x + wid;
   const u32 g = wid / (u32)group_windows, w = wid % (u32)group_windows;
   const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
   const u32 half = 1u << (c - 1), mask = (1u << c) - 1;
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(1024) void k_small_front(
     }
     u32 low = w * (u32)c;
     for (u32 bit = 0; bit < low && bit < 256; bit++) msk[bit >> 5] |= 1u << (bit & 31);
-    if (wid == 0) *heavy_count = 0;
+    if (gwid == 0) *heavy_count = 0;
   }
   __syncthreads();
   u32 my_key[kSmallIters], my_val[kSmallIters], my_rank[kSmallIters];
@@ -569,12 +579,12 @@ __global__ __launch_bounds__(1024) void k_small_front(
     }
   }
   __syncthreads();
-  const u32 slice = wid * (u32)n;  // this window's part of sorted_vals
+  const u32 slice = gwid * (u32)n;  // this window's part of sorted_vals
 #pragma unroll
   for (int it = 0; it < kSmallIters; it++)
     if (my_key[it] != invalid) sorted_vals[slice + off[my_key[it]] + my_rank[it]] = my_val[it];
   for (u32 b = threadIdx.x; b < n_buckets; b += kSmallThreads) {
-    const u32 gb = wid * n_buckets + b, st = slice + off[b];
+    const u32 gb = gwid * n_buckets + b, st = slice + off[b];
     bucket_start[gb] = st;
     bucket_end[gb] = st + hist[b];
   }
@@ -1495,8 +1505,12 @@ BP_DEV void tree_heavy_block(const u32* __restrict__ packed, const u32* __restri
   __shared__ u32 wave_sum[4 * 32];
   if (threadIdx.x == 0) n_list = 0;
   __syncthreads();
-  for (size_t b = blockIdx.x + (size_t)kTreeHeavyBlocks * threadIdx.x; b < nbt;
-       b += (size_t)kTreeHeavyBlocks * blockDim.x) {
+  // block h looks at one bucket of every run of kTreeHeavyBlocks: in run q the one at offset
+  // h + q + q / kTreeHeavyBlocks (mod kTreeHeavyBlocks), so that crowded buckets which sit a multiple of
+  // kTreeHeavyBlocks apart (bucket 0 of the same window of every problem of a batch) go to different blocks
+  for (size_t q = threadIdx.x; q * kTreeHeavyBlocks < nbt; q += blockDim.x) {
+    const size_t b = q * kTreeHeavyBlocks + ((blockIdx.x + q + q / kTreeHeavyBlocks) & (kTreeHeavyBlocks - 1));
+    if (b >= nbt) continue;
     const u32 cnt = end[b] - start[b];
     if (cnt > heavy_from && cnt <= heavy_max) {
       const u32 slot = atomicAdd(&n_list, 1u);
@@ -2075,6 +2089,30 @@ hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int
   return hipGetLastError();
 }
 
+// one wave per sum: lane l < count holds point l, a shuffle tree joins them (count <= 64)
+template <class C>
+__global__ __launch_bounds__(64) void k_window_group_sums(const u32* __restrict__ in, int count, u32* __restrict__ out) {
+  using F = typename C::Fq;
+  const int lane = threadIdx.x;
+  Xyzz acc = lane < count ? xyzz_load_aos(in + ((size_t)blockIdx.x * count + lane) * 32) : xyzz_identity<F>();
+  for (int off = 32; off > 0; off >>= 1) {
+    Xyzz o = xyzz_shfl_down(acc, off, 64);
+    if (lane < off) xyzz_add<F>(acc, o);
+  }
+  if (lane == 0) xyzz_store_aos(out + (size_t)blockIdx.x * 32, acc);
+}
+
+hipError_t launch_window_group_sums(int curve, const u32* in, int count, int n_sums, u32* out, hipStream_t st) {
+  if (count < 1 || count > 64 || n_sums < 1) return hipErrorInvalidValue;
+  if (curve == BP_SECP256K1)
+    hipLaunchKernelGGL(k_window_group_sums<Secp256k1>, dim3((unsigned)n_sums), dim3(64), 0, st, in, count, out);
+  else if (curve == BP_VESTA)
+    hipLaunchKernelGGL(k_window_group_sums<Vesta>, dim3((unsigned)n_sums), dim3(64), 0, st, in, count, out);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 static hipError_t msm_run_tail(int curve, const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st,
                                hipEvent_t ev_acc0, hipEvent_t ev_acc1, const u32* table_rec = nullptr);
 static hipError_t msm_sort_and_chunk(const MsmPlan& plan, const MsmWorkspace& ws, hipStream_t st, u32 window_base);
@@ -2096,13 +2134,16 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
                   {nullptr, nullptr}, {nullptr, nullptr}, {0, 0}};
   if (plan.groups == 1) sel = DigitGroups{0, 0, 0, 0, 0, 0, 0, {nullptr, nullptr}, {nullptr, nullptr}, {0, 0}};
   if (extra) {
-    // one extra point per group, split parts only
-    if (plan.groups != 2 || !p0.sel_half || (p1.n && !p1.sel_half) || n != p0.n + p1.n + 2) return hipErrorInvalidValue;
+    // one extra point per group; parts that go whole to one group only with the one-launch front end
+    // (the other front ends place an extra point behind the halves of split parts)
+    if (plan.groups != 2 || n != p0.n + p1.n + 2) return hipErrorInvalidValue;
+    if (!plan.small && (!p0.sel_half || (p1.n && !p1.sel_half))) return hipErrorInvalidValue;
     sel.n_extra = 2;
     for (int e = 0; e < 2; e++) {
       sel.extra_xy[e] = extra->xy[e];
       sel.extra_s[e] = extra->s[e];
       sel.extra_tab[e] = (u32)extra->tab_index[e];
+      sel.extra_stride[e] = (u32)extra->batch_stride[e];
     }
   } else if (n != p0.n + p1.n) {
     return hipErrorInvalidValue;
@@ -2115,9 +2156,13 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     if (!p0.sel_half && !p1.sel_half && p0.n && p1.n && p0.group_lo > p1.group_lo) return hipErrorInvalidValue;
   }
   if (plan.tab && (!table || !table->rec)) return hipErrorInvalidValue;
+  if (plan.batch > 1 && !plan.small) return hipErrorInvalidValue;
   if (plan.small) {
+    sel.s_stride0 = (u32)p0.batch_stride;
+    sel.s_stride1 = (u32)p1.batch_stride;
     // sorted entries and bucket bounds straight into the buffers the accumulation reads
-    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_small_front<C>, dim3((unsigned)plan.n_windows), dim3(kSmallThreads), 0, st,
+    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_small_front<C>, dim3((unsigned)(plan.n_windows / plan.batch), (unsigned)plan.batch),
+                                             dim3(kSmallThreads), 0, st,
                                              p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x, p0.y, p1.x, p1.y, ws.packed,
                                              sel, plan.c, plan.group_windows, plan.n_buckets, plan.wshift, ws.vals_b,
                                              ws.bucket_start, ws.bucket_end, ws.heavy_count,
@@ -2297,7 +2342,7 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
     size_t lane_cap = plan.mid ? 131072 : 65536;
     if (const char* ev = getenv("BP_MSM_TREE_LANES")) lane_cap = (size_t)atol(ev);  // tuning runs
     while (lanes > 1 && nbt * (size_t)lanes > lane_cap) lanes >>= 1;
-    const size_t per_bucket = plan.entries / (nbt ? nbt : 1);
+    const size_t per_bucket = plan.entries * (size_t)plan.batch / (nbt ? nbt : 1);
     while (lanes < 64 && (size_t)lanes * 32 < per_bucket) lanes <<= 1;
     // no more lanes than expected entries: every halving saves a level of the shuffle tree
     // (IPA round at 64 points: 0.21 -> 0.17 ms)

@@ -745,6 +745,377 @@ hipError_t launch_fill_one(int curve, u32* v, size_t n, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---- batches of aggregated range proofs -------------------------------------------------------
+// The same phases as above with one grid serving B proofs of one shape (blockIdx.y = proof): every
+// per-proof vector lives in an array of B rows, `n` (or 2n) elements apart, and what differs from proof
+// to proof -- the challenges, the tables of powers -- is read from device arrays with one row per proof.
+// Table row of proof b (RangeBatchTabs): z^(2+j), j < m | y^i, i < lo | y^(lo i), i < hi | the same two
+// for y^-1; y^k = ylo[k mod lo] * yhi[k / lo].
+
+// a_L || a_R of src/range/aggregate.rs:50-64 as the scalars of gs || hs (the A commitment, :81)
+template <class F>
+__global__ __launch_bounds__(256) void k_rangeb_commit_scalars(const uint64_t* __restrict__ values, u32 m, u32 n_bits, u32 n,
+                                                               u32* __restrict__ sa) {
+  const u32 sess = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const bool bit = (values[(size_t)sess * m + k / n_bits] >> (k % n_bits)) & 1;
+  const Fe one = fe_one<F>();
+  u32* row = sa + (size_t)sess * 2 * n * 8;
+  fe_store(row + (size_t)k * 8, bit ? one : fe_zero());
+  fe_store(row + ((size_t)n + k) * 8, bit ? fe_zero() : fe_neg<F>(one));
+}
+
+template <class F>
+BP_DEV Fe rangeb_power(const u32* __restrict__ lo_tab, const u32* __restrict__ hi_tab, u32 lo, u32 k) {
+  return fe_mul<F>(fe_load(lo_tab + (size_t)(k % lo) * 8), fe_load(hi_tab + (size_t)(k / lo) * 8));
+}
+
+// k_range_poly for B proofs; s_lr: s_L || s_R per proof (2n elements); zs: z per proof; partials: 3 per block and proof
+template <class F>
+__global__ __launch_bounds__(256) void k_rangeb_poly(const uint64_t* __restrict__ values, u32 m, u32 n_bits, u32 n,
+                                                     const u32* __restrict__ tabs, RangeBatchTabs tl,
+                                                     const u32* __restrict__ pow2, const u32* __restrict__ s_lr,
+                                                     const u32* __restrict__ zs, u32* __restrict__ l0, u32* __restrict__ r0,
+                                                     u32* __restrict__ r1, u32* __restrict__ partials) {
+  __shared__ u32 lds[3 * 32];
+  const u32 sess = blockIdx.y;
+  const u32* tab = tabs + (size_t)sess * tl.row * 8;
+  const Fe z = fe_load(zs + (size_t)sess * 8), one = fe_one<F>();
+  Fe d0 = fe_zero(), d1 = fe_zero(), d2 = fe_zero();
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    const u32 j = k / n_bits, i = k % n_bits;
+    const bool bit = (values[(size_t)sess * m + j] >> i) & 1;
+    const Fe al = bit ? one : fe_zero();
+    const Fe ar = bit ? fe_zero() : fe_neg<F>(one);
+    const Fe yk = rangeb_power<F>(tab + (size_t)tl.ylo * 8, tab + (size_t)tl.yhi * 8, tl.lo, k);
+    const size_t e = (size_t)sess * n + k;
+    const Fe sl = fe_load(s_lr + ((size_t)sess * 2 * n + k) * 8), sr = fe_load(s_lr + ((size_t)sess * 2 * n + n + k) * 8);
+    const Fe vl0 = fe_sub<F>(al, z);
+    const Fe vr0 = fe_add<F>(fe_mul<F>(yk, fe_add<F>(ar, z)), fe_mul<F>(fe_load(tab + (size_t)(tl.zpow + j) * 8), fe_load(pow2 + (size_t)i * 8)));
+    const Fe vr1 = fe_mul<F>(yk, sr);
+    fe_store(l0 + e * 8, vl0);
+    fe_store(r0 + e * 8, vr0);
+    fe_store(r1 + e * 8, vr1);
+    d0 = fe_mul<F>(vl0, vr1);
+    d1 = fe_mul<F>(sl, vr0);
+    d2 = fe_mul<F>(sl, vr1);
+  }
+  Fe t0 = block_reduce_add<F>(d0, lds);
+  Fe t1 = block_reduce_add<F>(d1, lds + 32);
+  Fe t2 = block_reduce_add<F>(d2, lds + 64);
+  if (threadIdx.x == 0) {
+    u32* p = partials + ((size_t)sess * gridDim.x + blockIdx.x) * 3 * 8;
+    fe_store(p, t0);
+    fe_store(p + 8, t1);
+    fe_store(p + 16, t2);
+  }
+}
+
+// out[b] = (t1, t2) of proof b; out may be host memory the device can write
+template <class F>
+__global__ __launch_bounds__(256) void k_rangeb_poly_final(const u32* __restrict__ partials, int blocks, u32* __restrict__ out) {
+  __shared__ u32 lds[2 * 32];
+  const u32 sess = blockIdx.x;
+  const u32* p = partials + (size_t)sess * blocks * 3 * 8;
+  Fe a = fe_zero(), b = fe_zero();
+  for (int i = threadIdx.x; i < blocks; i += blockDim.x) {
+    a = fe_add<F>(a, fe_add<F>(fe_load(p + ((size_t)i * 3 + 0) * 8), fe_load(p + ((size_t)i * 3 + 1) * 8)));
+    b = fe_add<F>(b, fe_load(p + ((size_t)i * 3 + 2) * 8));
+  }
+  Fe ta = block_reduce_add<F>(a, lds);
+  Fe tb = block_reduce_add<F>(b, lds + 32);
+  if (threadIdx.x == 0) {
+    fe_store(out + (size_t)sess * 16, ta);
+    fe_store(out + (size_t)sess * 16 + 8, tb);
+  }
+}
+
+// k_range_eval for B proofs: l, r are written as the vectors a, b of the proofs' inner-product arguments
+template <class F>
+__global__ __launch_bounds__(256) void k_rangeb_eval(const u32* __restrict__ l0, const u32* __restrict__ s_lr,
+                                                     const u32* __restrict__ r0, const u32* __restrict__ r1, u32 n,
+                                                     const u32* __restrict__ xs, u32* __restrict__ l, u32* __restrict__ r,
+                                                     u32* __restrict__ partials) {
+  __shared__ u32 lds[32];
+  const u32 sess = blockIdx.y;
+  const Fe x = fe_load(xs + (size_t)sess * 8);
+  Fe d = fe_zero();
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    const size_t e = (size_t)sess * n + k;
+    const Fe vl = fe_add<F>(fe_load(l0 + e * 8), fe_mul<F>(x, fe_load(s_lr + ((size_t)sess * 2 * n + k) * 8)));
+    const Fe vr = fe_add<F>(fe_load(r0 + e * 8), fe_mul<F>(x, fe_load(r1 + e * 8)));
+    fe_store(l + e * 8, vl);
+    fe_store(r + e * 8, vr);
+    d = fe_mul<F>(vl, vr);
+  }
+  Fe t = block_reduce_add<F>(d, lds);
+  if (threadIdx.x == 0) fe_store(partials + ((size_t)sess * gridDim.x + blockIdx.x) * 8, t);
+}
+
+// out[b] = sum of proof b's partial sums (one block per proof); out may be host memory the device can write
+template <class F>
+__global__ __launch_bounds__(256) void k_rangeb_sum_final(const u32* __restrict__ partials, int blocks, u32* __restrict__ out) {
+  __shared__ u32 lds[32];
+  const u32 sess = blockIdx.x;
+  Fe acc = fe_zero();
+  for (int i = threadIdx.x; i < blocks; i += blockDim.x) acc = fe_add<F>(acc, fe_load(partials + ((size_t)sess * blocks + i) * 8));
+  Fe tot = block_reduce_add<F>(acc, lds);
+  if (threadIdx.x == 0) fe_store(out + (size_t)sess * 8, tot);
+}
+
+// start of B inner-product arguments over gs, hs' = y^-i hs (src/range/aggregate.rs:148-153): generator
+// coefficients cg = 1, ch_i = y^-i (what bp_ipa_scale_h does for one session)
+template <class F>
+__global__ __launch_bounds__(256) void k_ipab_init(const u32* __restrict__ tabs, RangeBatchTabs tl, u32 n, u32* __restrict__ cg,
+                                                   u32* __restrict__ ch) {
+  const u32 sess = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const u32* tab = tabs + (size_t)sess * tl.row * 8;
+  const size_t e = (size_t)sess * n + k;
+  fe_store(cg + e * 8, fe_one<F>());
+  fe_store(ch + e * 8, rangeb_power<F>(tab + (size_t)tl.yilo * 8, tab + (size_t)tl.yihi * 8, tl.lo, k));
+}
+
+// k_ipa_round_prep for B sessions: rows of n0 elements, dots: 4 elements per session, factors: one per session
+template <class F>
+__global__ __launch_bounds__(1024) void k_ipab_round_prep(const u32* __restrict__ a, const u32* __restrict__ b,
+                                                          const u32* __restrict__ cg, const u32* __restrict__ ch, u32 n0,
+                                                          u32 half, const u32* __restrict__ factors, u32* __restrict__ eg,
+                                                          u32* __restrict__ eh, u32* __restrict__ dots) {
+  const size_t row = (size_t)blockIdx.y * n0 * 8;
+  a += row; b += row; cg += row; ch += row; eg += row; eh += row;
+  dots += (size_t)blockIdx.y * 32;
+  if (blockIdx.x == 0) {
+    __shared__ u32 lds[2 * 16 * 8];
+    Fe accl = fe_zero(), accr = fe_zero();
+    for (u32 i = threadIdx.x; i < half; i += blockDim.x) {
+      Fe al = fe_load(a + (size_t)i * 8), ah = fe_load(a + (size_t)(i + half) * 8);
+      Fe bl = fe_load(b + (size_t)i * 8), bh = fe_load(b + (size_t)(i + half) * 8);
+      accl = fe_add<F>(accl, fe_mul<F>(al, bh));
+      accr = fe_add<F>(accr, fe_mul<F>(ah, bl));
+    }
+    Fe tl = block_reduce_add<F>(accl, lds);
+    Fe tr = block_reduce_add<F>(accr, lds + 16 * 8);
+    if (threadIdx.x == 0) {
+      const Fe f = fe_load(factors + (size_t)blockIdx.y * 8);
+      fe_store(dots, tl);
+      fe_store(dots + 8, tr);
+      fe_store(dots + 16, fe_mul<F>(tl, f));
+      fe_store(dots + 24, fe_mul<F>(tr, f));
+    }
+    return;
+  }
+  const u32 k = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
+  if (k >= n0) return;
+  const u32 i = k & (2 * half - 1);
+  const u32 other = i >= half ? i - half : i + half;
+  fe_store(eg + (size_t)k * 8, fe_mul<F>(fe_load(cg + (size_t)k * 8), fe_load(a + (size_t)other * 8)));
+  fe_store(eh + (size_t)k * 8, fe_mul<F>(fe_load(ch + (size_t)k * 8), fe_load(b + (size_t)other * 8)));
+}
+
+// k_ipa_fold_prep for B sessions: challenges xs, xis: one per session
+template <class F>
+__global__ __launch_bounds__(1024) void k_ipab_fold_prep(const u32* __restrict__ a, const u32* __restrict__ b,
+                                                         u32* __restrict__ a2, u32* __restrict__ b2, u32* __restrict__ cg,
+                                                         u32* __restrict__ ch, u32 n0, u32 half, const u32* __restrict__ xs,
+                                                         const u32* __restrict__ xis, const u32* __restrict__ factors,
+                                                         u32* __restrict__ eg, u32* __restrict__ eh, u32* __restrict__ dots) {
+  const size_t row = (size_t)blockIdx.y * n0 * 8;
+  a += row; b += row; a2 += row; b2 += row; cg += row; ch += row; eg += row; eh += row;
+  dots += (size_t)blockIdx.y * 32;
+  const Fe x = fe_load(xs + (size_t)blockIdx.y * 8), xi = fe_load(xis + (size_t)blockIdx.y * 8);
+  const u32 q = half / 2;  // half of the next round
+  if (blockIdx.x == 0) {
+    __shared__ u32 lds[2 * 16 * 8];
+    Fe accl = fe_zero(), accr = fe_zero();
+    for (u32 i = threadIdx.x; i < q; i += blockDim.x) {
+      Fe al = fe_mul2<F>(fe_load(a + (size_t)i * 8), x, fe_load(a + (size_t)(i + half) * 8), xi);
+      Fe ah = fe_mul2<F>(fe_load(a + (size_t)(i + q) * 8), x, fe_load(a + (size_t)(i + q + half) * 8), xi);
+      Fe bl = fe_mul2<F>(fe_load(b + (size_t)i * 8), xi, fe_load(b + (size_t)(i + half) * 8), x);
+      Fe bh = fe_mul2<F>(fe_load(b + (size_t)(i + q) * 8), xi, fe_load(b + (size_t)(i + q + half) * 8), x);
+      fe_store(a2 + (size_t)i * 8, al);
+      fe_store(a2 + (size_t)(i + q) * 8, ah);
+      fe_store(b2 + (size_t)i * 8, bl);
+      fe_store(b2 + (size_t)(i + q) * 8, bh);
+      accl = fe_add<F>(accl, fe_mul<F>(al, bh));
+      accr = fe_add<F>(accr, fe_mul<F>(ah, bl));
+    }
+    Fe tl = block_reduce_add<F>(accl, lds);
+    Fe tr = block_reduce_add<F>(accr, lds + 16 * 8);
+    if (threadIdx.x == 0) {
+      const Fe f = fe_load(factors + (size_t)blockIdx.y * 8);
+      fe_store(dots, tl);
+      fe_store(dots + 8, tr);
+      fe_store(dots + 16, fe_mul<F>(tl, f));
+      fe_store(dots + 24, fe_mul<F>(tr, f));
+    }
+    return;
+  }
+  const u32 k = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
+  if (k >= n0) return;
+  const bool upper = (k & (2 * half - 1)) >= half;
+  const u32 i = k & (half - 1);
+  const u32 other = i >= q ? i - q : i + q;
+  {
+    Fe c = fe_mul<F>(fe_load(cg + (size_t)k * 8), upper ? x : xi);
+    fe_store(cg + (size_t)k * 8, c);
+    Fe av = fe_mul2<F>(fe_load(a + (size_t)other * 8), x, fe_load(a + (size_t)(other + half) * 8), xi);
+    fe_store(eg + (size_t)k * 8, fe_mul<F>(c, av));
+  }
+  {
+    Fe c = fe_mul<F>(fe_load(ch + (size_t)k * 8), upper ? xi : x);
+    fe_store(ch + (size_t)k * 8, c);
+    Fe bv = fe_mul2<F>(fe_load(b + (size_t)other * 8), xi, fe_load(b + (size_t)(other + half) * 8), x);
+    fe_store(eh + (size_t)k * 8, fe_mul<F>(c, bv));
+  }
+}
+
+// the last fold of B sessions (two elements to one): out[b] = (a', b') of session b, which may be host
+// memory the device can write
+template <class F>
+__global__ __launch_bounds__(64) void k_ipab_last_fold(const u32* __restrict__ a, const u32* __restrict__ b, u32 n0,
+                                                       const u32* __restrict__ xs, const u32* __restrict__ xis, int batch,
+                                                       u32* __restrict__ out) {
+  const int sess = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sess >= batch) return;
+  const size_t row = (size_t)sess * n0 * 8;
+  const Fe x = fe_load(xs + (size_t)sess * 8), xi = fe_load(xis + (size_t)sess * 8);
+  fe_store(out + (size_t)sess * 16, fe_mul2<F>(fe_load(a + row), x, fe_load(a + row + 8), xi));
+  fe_store(out + (size_t)sess * 16 + 8, fe_mul2<F>(fe_load(b + row), xi, fe_load(b + row + 8), x));
+}
+
+hipError_t launch_rangeb_commit_scalars(int curve, const uint64_t* values, u32 m, u32 n_bits, u32 n, int batch, u32* sa,
+                                        hipStream_t st) {
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_rangeb_commit_scalars<F>, dim3((n + 255) / 256, (unsigned)batch), dim3(256), 0, st,
+                                        values, m, n_bits, n, sa));
+  return hipGetLastError();
+}
+
+hipError_t launch_rangeb_poly(int curve, const uint64_t* values, u32 m, u32 n_bits, u32 n, int batch, const u32* tabs,
+                              RangeBatchTabs tl, const u32* pow2, const u32* s_lr, const u32* zs, u32* l0, u32* r0, u32* r1,
+                              u32* partials, u32* out, hipStream_t st) {
+  const unsigned blocks = (n + 255) / 256;
+  DISPATCH_FR(curve, {
+    hipLaunchKernelGGL(k_rangeb_poly<F>, dim3(blocks, (unsigned)batch), dim3(256), 0, st, values, m, n_bits, n, tabs, tl, pow2,
+                       s_lr, zs, l0, r0, r1, partials);
+    hipLaunchKernelGGL(k_rangeb_poly_final<F>, dim3((unsigned)batch), dim3(256), 0, st, partials, (int)blocks, out);
+  });
+  return hipGetLastError();
+}
+
+hipError_t launch_rangeb_eval(int curve, const u32* l0, const u32* s_lr, const u32* r0, const u32* r1, u32 n, int batch,
+                              const u32* xs, u32* l, u32* r, u32* partials, u32* out, hipStream_t st) {
+  const unsigned blocks = (n + 255) / 256;
+  DISPATCH_FR(curve, {
+    hipLaunchKernelGGL(k_rangeb_eval<F>, dim3(blocks, (unsigned)batch), dim3(256), 0, st, l0, s_lr, r0, r1, n, xs, l, r, partials);
+    hipLaunchKernelGGL(k_rangeb_sum_final<F>, dim3((unsigned)batch), dim3(256), 0, st, partials, (int)blocks, out);
+  });
+  return hipGetLastError();
+}
+
+hipError_t launch_ipab_init(int curve, const u32* tabs, RangeBatchTabs tl, u32 n, int batch, u32* cg, u32* ch, hipStream_t st) {
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipab_init<F>, dim3((n + 255) / 256, (unsigned)batch), dim3(256), 0, st, tabs, tl, n, cg, ch));
+  return hipGetLastError();
+}
+
+hipError_t launch_ipab_round_prep(int curve, const u32* a, const u32* b, const u32* cg, const u32* ch, u32 n0, u32 half,
+                                  int batch, const u32* factors, u32* eg, u32* eh, u32* dots, hipStream_t st) {
+  if (half > kIpaPrepMaxHalf) return hipErrorInvalidValue;
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipab_round_prep<F>, dim3(1 + (n0 + 1023) / 1024, (unsigned)batch), dim3(1024), 0, st, a,
+                                        b, cg, ch, n0, half, factors, eg, eh, dots));
+  return hipGetLastError();
+}
+
+hipError_t launch_ipab_fold_prep(int curve, const u32* a, const u32* b, u32* a2, u32* b2, u32* cg, u32* ch, u32 n0, u32 half,
+                                 int batch, const u32* xs, const u32* xis, const u32* factors, u32* eg, u32* eh, u32* dots,
+                                 hipStream_t st) {
+  if (half < 2 || half / 2 > kIpaPrepMaxHalf) return hipErrorInvalidValue;
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipab_fold_prep<F>, dim3(1 + (n0 + 1023) / 1024, (unsigned)batch), dim3(1024), 0, st, a,
+                                        b, a2, b2, cg, ch, n0, half, xs, xis, factors, eg, eh, dots));
+  return hipGetLastError();
+}
+
+hipError_t launch_ipab_last_fold(int curve, const u32* a, const u32* b, u32 n0, int batch, const u32* xs, const u32* xis,
+                                 u32* out, hipStream_t st) {
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipab_last_fold<F>, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, a, b, n0, xs,
+                                        xis, batch, out));
+  return hipGetLastError();
+}
+
+// Blinders s_L || s_R of B proofs from B SplitMix64 streams (the generator of the seeded drivers and
+// benches; a production caller uploads blinders from its own source): element i of proof b is draw number
+// first_draw + i of the stream seeded seeds[b], a draw being four consecutive outputs as little-endian
+// limbs, taken as it is when below the modulus (Montgomery-encoded).  The host-side generator rejects a
+// draw at or above the modulus and moves on, which shifts every later draw: such a draw sets *rejected
+// here and the caller falls back to the host.
+template <class F>
+__global__ __launch_bounds__(256) void k_rangeb_blinders(const uint64_t* __restrict__ seeds, u32 first_draw, u32 count,
+                                                         u32* __restrict__ out, u32* __restrict__ rejected) {
+  const u32 sess = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint64_t seed = seeds[sess];
+  Fe v;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint64_t z = seed + (4ull * (first_draw + i) + (uint64_t)k + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    v.v[2 * k] = (u32)z;
+    v.v[2 * k + 1] = (u32)(z >> 32);
+  }
+  // v >= modulus?
+  u32 bw = 0;
+#pragma unroll
+  for (int t = 0; t < 8; t++) (void)__builtin_subc(v.v[t], F::mod(t), bw, &bw);
+  if (bw == 0) atomicOr(rejected, 1u);
+  fe_store(out + ((size_t)sess * count + i) * 8, fe_to_mont<F>(v));
+}
+
+// x^e by square and multiply
+template <class F>
+BP_DEV Fe fe_pow_u32(Fe x, u32 e) {
+  Fe acc = fe_one<F>();
+  while (e) {
+    if (e & 1) acc = fe_mul<F>(acc, x);
+    x = fe_sqr<F>(x);
+    e >>= 1;
+  }
+  return acc;
+}
+
+// table row of every proof (RangeBatchTabs) from its y, y^-1 and z: yz = B values of y, then B of y^-1, then B of z
+template <class F>
+__global__ __launch_bounds__(256) void k_rangeb_tables(const u32* __restrict__ yz, RangeBatchTabs tl, u32 m, u32* __restrict__ tabs) {
+  const u32 sess = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= tl.row) return;
+  const size_t B = gridDim.y;
+  const Fe y = fe_load(yz + (size_t)sess * 8), yi = fe_load(yz + (B + sess) * 8), z = fe_load(yz + (2 * B + sess) * 8);
+  Fe v;
+  if (t >= tl.yihi) v = fe_pow_u32<F>(yi, (t - tl.yihi) * tl.lo);
+  else if (t >= tl.yilo) v = fe_pow_u32<F>(yi, t - tl.yilo);
+  else if (t >= tl.yhi) v = fe_pow_u32<F>(y, (t - tl.yhi) * tl.lo);
+  else if (t >= tl.ylo) v = fe_pow_u32<F>(y, t - tl.ylo);
+  else v = fe_pow_u32<F>(z, 2 + (t - tl.zpow));
+  (void)m;
+  fe_store(tabs + ((size_t)sess * tl.row + t) * 8, v);
+}
+
+hipError_t launch_rangeb_blinders(int curve, const uint64_t* seeds, u32 first_draw, u32 count, int batch, u32* out, u32* rejected,
+                                  hipStream_t st) {
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_rangeb_blinders<F>, dim3((count + 255) / 256, (unsigned)batch), dim3(256), 0, st, seeds,
+                                        first_draw, count, out, rejected));
+  return hipGetLastError();
+}
+
+hipError_t launch_rangeb_tables(int curve, const u32* yz, RangeBatchTabs tl, u32 m, int batch, u32* tabs, hipStream_t st) {
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_rangeb_tables<F>, dim3((tl.row + 255) / 256, (unsigned)batch), dim3(256), 0, st, yz, tl, m,
+                                        tabs));
+  return hipGetLastError();
+}
+
 // ---- integer multiply-accumulate peak probe -----------------------------------
 // 32 independent 64-bit accumulators per lane, 8 v_mad_u64_u32 each per loop
 // iteration (256 per iteration), nothing else in the loop but its counter: the

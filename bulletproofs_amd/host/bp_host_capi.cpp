@@ -254,7 +254,92 @@ struct SeededRandom : RandomSource {
       }
     }
   }
+  bool splitmix_state(uint64_t* state) const override { *state = st; return true; }
+  void splitmix_skip(size_t draws) override { st += 4 * (uint64_t)draws * 0x9E3779B97F4A7C15ull; }
 };
+
+// The same stream without the device hand-over: the batched prover then uploads the blinders
+template <class Fr>
+struct SeededRandomHostOnly : SeededRandom<Fr> {
+  using SeededRandom<Fr>::SeededRandom;
+  bool splitmix_state(uint64_t*) const override { return false; }
+};
+
+// `batch` aggregated range proofs through RangeAggregate::prove_batch, `reps` times from one host thread;
+// proof b proves values[b], gamma[b] with the random stream seed_rand + b and the challenges of seed_chal + b.
+template <class Fq, class Fr, int CURVE>
+int range_prove_batch(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx, const uint64_t* hy,
+                      const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma, size_t batch, size_t m,
+                      unsigned n_bits, uint64_t seed_rand, uint64_t seed_chal, int reps, int host_blinders, int verify,
+                      uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_lr, double* batch_ms, int* ok) {
+  using R = RangeAggregate<Fq, Fr, CURVE>;
+  using PO = PointOps<Fq, Fr>;
+  const size_t n = (size_t)n_bits * m;
+  typename R::Crs crs;
+  crs.ipa.gs = unpack(gx, gy, nullptr, n);
+  crs.ipa.hs = unpack(hx, hy, nullptr, n);
+  auto pt = [&](int k) { Affine a; memcpy(a.x, ugh_xy + 8 * k, 32); memcpy(a.y, ugh_xy + 8 * k + 4, 32); a.inf = 0; return a; };
+  crs.ipa.u = pt(0); crs.g = pt(1); crs.h = pt(2);
+  crs.n = n;
+  struct Release {
+    typename R::Crs& c; bp_range_batch* rb = nullptr;
+    ~Release() { bp_range_batch_free(rb); bp_bases_free(c.ghb); bp_bases_free(c.gh); }
+  } release{crs};
+  R::register_batch_bases(ctx, crs);
+  check(ctx, bp_range_batch_begin(ctx, crs.ghb, batch, m, n_bits, &release.rb), "bp_range_batch_begin");
+  struct Timing { bp_ctx* c; Timing(bp_ctx* c_) : c(c_) { bp_set_timing(c, 0); } ~Timing() { bp_set_timing(c, 1); } } timing(ctx);
+  const std::vector<Scalar> gam = unpack_s(gamma, batch * m);
+  std::vector<RangeProof> proofs;
+  double total = 0;
+  for (int r = 0; r < reps + 1; r++) {  // the first pass grows the context's workspace and is not timed
+    std::vector<SeededTranscript<Fr>> tr;
+    std::vector<SeededRandom<Fr>> rd;
+    std::vector<SeededRandomHostOnly<Fr>> rh;
+    tr.reserve(batch); rd.reserve(batch); rh.reserve(batch);
+    std::vector<Transcript*> tp(batch);
+    std::vector<RandomSource*> rp(batch);
+    for (size_t b = 0; b < batch; b++) {
+      tr.emplace_back(seed_chal + b);
+      rd.emplace_back(seed_rand + b);
+      rh.emplace_back(seed_rand + b);
+      tp[b] = &tr[b];
+      rp[b] = host_blinders ? (RandomSource*)&rh[b] : (RandomSource*)&rd[b];
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    proofs = R::prove_batch(ctx, crs, release.rb, values, gam.data(), m, n_bits, tp.data(), rp.data());
+    auto t1 = std::chrono::steady_clock::now();
+    if (r > 0) total += std::chrono::duration<double, std::milli>(t1 - t0).count();
+  }
+  *batch_ms = total / reps;
+  size_t k = 0;
+  while (((size_t)1 << k) < n) k++;
+  for (size_t b = 0; b < batch; b++) {
+    const RangeProof& p = proofs[b];
+    uint64_t* op = out_points + 48 * b;
+    memcpy(op, p.a.xyz, 96); memcpy(op + 12, p.s.xyz, 96); memcpy(op + 24, p.tt1.xyz, 96); memcpy(op + 36, p.tt2.xyz, 96);
+    uint64_t* os = out_scalars + 20 * b;
+    memcpy(os, p.tao_x.l, 32); memcpy(os + 4, p.mu.l, 32); memcpy(os + 8, p.t_hat.l, 32);
+    memcpy(os + 12, p.ipa.a.l, 32); memcpy(os + 16, p.ipa.b.l, 32);
+    for (size_t j = 0; j < p.ipa.L.size(); j++) {
+      memcpy(out_lr + (b * k + j) * 24, p.ipa.L[j].xyz, 96);
+      memcpy(out_lr + (b * k + j) * 24 + 12, p.ipa.R[j].xyz, 96);
+    }
+  }
+  *ok = 1;
+  if (verify) {
+    // every proof through the single-proof verifier over the usual base set
+    R::register_bases(ctx, crs, n);
+    for (size_t b = 0; b < batch; b++) {
+      std::vector<Projective> vcom(m);
+      for (size_t j = 0; j < m; j++)
+        vcom[j] = PO::lower(hx_add<Fq>(crs.g_tab.mul(R::from_u64(values[b * m + j])), crs.h_tab.mul(gam[b * m + j])));
+      SeededTranscript<Fr> t2(seed_chal + b);
+      SeededRandom<Fr> vrng((seed_rand + b) ^ 0x5EEDull);
+      if (!R::verify(ctx, crs, vcom, n_bits, proofs[b], t2, vrng)) *ok = 0;
+    }
+  }
+  return 0;
+}
 
 template <class Fq, class Fr, int CURVE>
 int range_roundtrip(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx, const uint64_t* hy,
@@ -582,6 +667,37 @@ int bph_range_agg_verify_batch(bp_ctx* ctx, int curve, const uint64_t* gx, const
       return range_verify_batch<VestaFq, VestaFr, BP_VESTA>(ctx, gx, gy, hx, hy, ugh_xy, values, gamma, m, n_bits, seed_rand,
                                                            seed_chal, distinct, batch, tamper, collect_ms, device_merge_ms,
                                                            host_merge_ms, ok_device, ok_host, direct_ms, ok_direct);
+    return BP_E_CURVE;
+  } catch (const VerificationError&) {
+    return BPH_E_VERIFY;
+  } catch (const std::invalid_argument&) {
+    return BP_E_ARG;
+  } catch (const std::exception&) {
+    return BP_E_HIP;
+  }
+}
+
+// batch x (m values of n_bits bits) aggregated range proofs proved together (RangeAggregate::prove_batch),
+// reps times; batch_ms: wall time of one batch on the calling thread.  values: batch x m; gamma: batch x m
+// scalars; proof b uses the seeds seed_rand + b, seed_chal + b.  host_blinders != 0: the blinders are drawn on
+// the host and uploaded.  verify != 0: every proof is then checked by RangeAggregate::verify (ok).  Outputs
+// per proof as bph_range_agg_roundtrip's: out_points batch x 48, out_scalars batch x 20, out_lr batch x
+// log2(N) x 24 u64.
+int bph_range_agg_prove_batch(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_t* gy, const uint64_t* hx,
+                              const uint64_t* hy, const uint64_t* ugh_xy, const uint64_t* values, const uint64_t* gamma,
+                              size_t batch, size_t m, unsigned n_bits, uint64_t seed_rand, uint64_t seed_chal, int reps,
+                              int host_blinders, int verify, uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_lr,
+                              double* batch_ms, int* ok) {
+  if (reps < 1 || batch < 1 || !out_points || !out_scalars || !out_lr || !batch_ms || !ok) return BP_E_ARG;
+  try {
+    if (curve == BP_SECP256K1)
+      return range_prove_batch<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(ctx, gx, gy, hx, hy, ugh_xy, values, gamma, batch, m,
+                                                                      n_bits, seed_rand, seed_chal, reps, host_blinders, verify,
+                                                                      out_points, out_scalars, out_lr, batch_ms, ok);
+    if (curve == BP_VESTA)
+      return range_prove_batch<VestaFq, VestaFr, BP_VESTA>(ctx, gx, gy, hx, hy, ugh_xy, values, gamma, batch, m, n_bits, seed_rand,
+                                                          seed_chal, reps, host_blinders, verify, out_points, out_scalars,
+                                                          out_lr, batch_ms, ok);
     return BP_E_CURVE;
   } catch (const VerificationError&) {
     return BPH_E_VERIFY;

@@ -13,6 +13,12 @@ namespace host {
 
 struct RandomSource {
   virtual Scalar scalar() = 0;  // uniform element of Fr, Montgomery form
+  // A source whose scalars are consecutive draws of a SplitMix64 stream (four outputs per draw, little-endian
+  // limbs, a draw at or above the group order discarded) reports the stream's state, and skips `draws` draws
+  // that were all accepted: the batched prover then has the device produce a proof's 2N blinders from that
+  // state (bp_range_batch_commit) instead of uploading them.  Any other source returns false.
+  virtual bool splitmix_state(uint64_t* state) const { (void)state; return false; }
+  virtual void splitmix_skip(size_t draws) { (void)draws; }
   virtual ~RandomSource() {}
 };
 
@@ -36,6 +42,7 @@ struct RangeAggregate {
     Affine g, h;
     size_t n = 0;            // N = n_bits * m actually used
     bp_bases* gh = nullptr;  // gs[0..N) || hs[0..N) || ipa.u
+    bp_bases* ghb = nullptr; // gs[0..N) || hs[0..N) || ipa.u || g || h with window tables (register_batch_bases)
     FixedBase<Fq, Fr> g_tab, h_tab, u_tab;  // multiples of g, h, ipa.u (built by register_bases)
   };
 
@@ -161,6 +168,100 @@ struct RangeAggregate {
     pr.ipa = I::prove_resident(ctx, crs.gh, 0, n, y_inv_pows.data(), 2 * n, xe, l, r, t);  // :166
     tr.mark("ipa rounds");
     return pr;
+  }
+
+  // The base set of prove_batch: every point a proof's commitments use, so that A, S, T1, T2 and the
+  // rounds' L, R all come from passes over window tables.  Freed by the caller (bp_bases_free(crs.ghb)).
+  static void register_batch_bases(bp_ctx* ctx, Crs& crs) {
+    const size_t n = crs.n, total = 2 * n + 3;
+    std::vector<uint64_t> x(4 * total), y(4 * total);
+    std::vector<uint8_t> inf(total, 0);
+    auto put = [&](size_t i, const Affine& p) { memcpy(&x[4 * i], p.x, 32); memcpy(&y[4 * i], p.y, 32); inf[i] = p.inf; };
+    for (size_t i = 0; i < n; i++) { put(i, crs.ipa.gs[i]); put(n + i, crs.ipa.hs[i]); }
+    put(2 * n, crs.ipa.u); put(2 * n + 1, crs.g); put(2 * n + 2, crs.h);
+    check(ctx, bp_bases_register(ctx, CURVE, x.data(), y.data(), inf.data(), total, &crs.ghb), "bp_bases_register");
+    check(ctx, bp_bases_precompute(crs.ghb), "bp_bases_precompute");
+  }
+
+  // B = bp_range_batch_size(rb) proofs of src/range/aggregate.rs:23-170 proved together: the phases of
+  // prove() above with every device step shared by the batch (bp_range_batch_*), the transcripts and the
+  // random sources kept apart.  values: B x m, gamma: B x m; proof b talks to ts[b] and draws from rngs[b] in
+  // prove()'s order, so it is the proof prove() returns for the same inputs.
+  static std::vector<RangeProof> prove_batch(bp_ctx* ctx, const Crs& crs, bp_range_batch* rb, const uint64_t* values,
+                                             const Scalar* gamma, size_t m, unsigned n_bits, Transcript* const* ts,
+                                             RandomSource* const* rngs) {
+    const size_t B = bp_range_batch_size(rb), n = (size_t)n_bits * m;
+    if (n != crs.n || B == 0) throw std::invalid_argument("CRS registered for another size");
+    std::vector<RangeProof> prs(B);
+    std::vector<Scalar> alpha(B), rho(B);
+    for (size_t b = 0; b < B; b++) { alpha[b] = rngs[b]->scalar(); rho[b] = rngs[b]->scalar(); }   // :66-67
+    std::vector<Projective> pts(2 * B);
+    {
+      // :68-73 -- blinders from the device when every source is a stream it can reproduce
+      std::vector<uint64_t> seeds(B);
+      bool on_device = CURVE == BP_SECP256K1;  // a 256-bit draw is below Vesta's order one time in four
+      for (size_t b = 0; b < B && on_device; b++) on_device = rngs[b]->splitmix_state(&seeds[b]);
+      int rc = BP_E_STATE;
+      if (on_device) rc = bp_range_batch_commit(rb, values, nullptr, seeds.data(), 0, alpha[0].l, rho[0].l, pts[0].xyz);
+      if (on_device && rc == BP_OK) {
+        for (size_t b = 0; b < B; b++) rngs[b]->splitmix_skip(2 * n);
+      } else if (rc == BP_E_STATE) {
+        std::vector<Scalar> s_lr(B * 2 * n);
+        for (size_t b = 0; b < B; b++)
+          for (size_t i = 0; i < 2 * n; i++) s_lr[b * 2 * n + i] = rngs[b]->scalar();
+        rc = bp_range_batch_commit(rb, values, s_lr[0].l, nullptr, 0, alpha[0].l, rho[0].l, pts[0].xyz);
+      }
+      check(ctx, rc, "bp_range_batch_commit");                                                     // :80-83
+    }
+    std::vector<Scalar> y(B), z(B), y_inv;
+    for (size_t b = 0; b < B; b++) {
+      prs[b].a = pts[2 * b]; prs[b].s = pts[2 * b + 1];
+      ts[b]->prover_points(&pts[2 * b], 2);                                                        // :85
+      y[b] = ts[b]->verifier_scalar(); z[b] = ts[b]->verifier_scalar();                            // :86
+    }
+    S::batch_inv(y, y_inv);
+    std::vector<Scalar> t12(2 * B), tsc(4 * B);
+    check(ctx, bp_range_batch_poly(rb, y[0].l, y_inv[0].l, z[0].l, t12[0].l), "bp_range_batch_poly");  // :88-120
+    for (size_t b = 0; b < B; b++) {
+      tsc[4 * b] = t12[2 * b]; tsc[4 * b + 1] = rngs[b]->scalar();                                 // :121-122
+      tsc[4 * b + 2] = t12[2 * b + 1]; tsc[4 * b + 3] = rngs[b]->scalar();
+    }
+    check(ctx, bp_range_batch_tcommit(rb, tsc[0].l, pts[0].xyz), "bp_range_batch_tcommit");        // :126-127
+    std::vector<Scalar> x(B), xi;
+    for (size_t b = 0; b < B; b++) {
+      prs[b].tt1 = pts[2 * b]; prs[b].tt2 = pts[2 * b + 1];
+      ts[b]->prover_points(&pts[2 * b], 2);                                                        // :129
+      x[b] = ts[b]->verifier_scalar();                                                             // :133
+      Scalar sigma = S::zero(), zpow = S::mul(z[b], z[b]);                                         // :136-139
+      for (size_t j = 0; j < m; j++) { sigma = S::add(sigma, S::mul(zpow, gamma[b * m + j])); zpow = S::mul(zpow, z[b]); }
+      prs[b].tao_x = S::add(S::add(S::mul(tsc[4 * b + 1], x[b]), S::mul(tsc[4 * b + 3], S::mul(x[b], x[b]))), sigma);  // :140
+      prs[b].mu = S::add(alpha[b], S::mul(rho[b], x[b]));                                          // :142
+    }
+    std::vector<Scalar> t_hat(B), xe(B);
+    check(ctx, bp_range_batch_eval(rb, x[0].l, t_hat[0].l), "bp_range_batch_eval");                // :143-146
+    for (size_t b = 0; b < B; b++) {
+      prs[b].t_hat = t_hat[b];
+      Scalar msg[3] = {prs[b].tao_x, prs[b].mu, prs[b].t_hat};
+      ts[b]->prover_scalars(msg, 3);                                                               // :159
+      xe[b] = ts[b]->verifier_scalar();                                                            // src/ipa/extended.rs:22
+    }
+    check(ctx, bp_range_batch_ipa_begin(rb, xe[0].l), "bp_range_batch_ipa_begin");                 // :148-166
+    while (bp_range_batch_ipa_len(rb) != 1) {
+      check(ctx, bp_range_batch_round_lr(rb, pts[0].xyz), "bp_range_batch_round_lr");              // src/ipa/mod.rs:43-71
+      for (size_t b = 0; b < B; b++) {
+        ts[b]->prover_points(&pts[2 * b], 2);                                                      // :75
+        x[b] = ts[b]->verifier_scalar();                                                           // :77
+        prs[b].ipa.L.push_back(pts[2 * b]); prs[b].ipa.R.push_back(pts[2 * b + 1]);
+      }
+      S::batch_inv(x, xi);                                                                         // :78
+      check(ctx, bp_range_batch_round_fold(rb, x[0].l, xi[0].l), "bp_range_batch_round_fold");     // :80-92
+    }
+    check(ctx, bp_range_batch_finish(rb, t12[0].l), "bp_range_batch_finish");
+    for (size_t b = 0; b < B; b++) {
+      prs[b].ipa.a = t12[2 * b]; prs[b].ipa.b = t12[2 * b + 1];
+      ts[b]->prover_scalars(&t12[2 * b], 2);                                                       // :97
+    }
+    return prs;
   }
 
   // src/range/aggregate.rs:173-282 as ONE deferred MSM.  The reference evaluates three group

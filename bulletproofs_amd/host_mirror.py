@@ -93,6 +93,40 @@ def range_aggregate_roundtrip(ctx: Context, curve, gs, hs, ugh_xy, values, gamma
                 verify_ms=tv.value, ok=bool(ok.value))
 
 
+hlib.bph_range_agg_prove_batch.restype = ci
+hlib.bph_range_agg_prove_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, sz, C.c_uint, C.c_uint64, C.c_uint64, ci, ci, ci,
+                                           vp, vp, vp, C.POINTER(C.c_double), C.POINTER(ci)]
+
+
+def range_aggregate_prove_batch(ctx: Context, curve, gs, hs, ugh_xy, values, gamma, n_bits, seed_rand=1, seed_chal=2, reps=1,
+                                host_blinders=False, verify=False):
+    """B aggregated range proofs proved together from one host thread (RangeAggregate::prove_batch over
+    bp_range_batch_*): values (B, m), gamma (B, m, 4); proof b uses the seeds seed_rand + b, seed_chal + b.
+    Returns one dict per proof (keys as range_aggregate_roundtrip's) and the wall time of a batch."""
+    gx, gy, _ = _pts(gs)
+    hx, hy, _ = _pts(hs)
+    values = np.ascontiguousarray(values, dtype=np.uint64)
+    gamma = np.ascontiguousarray(gamma, dtype=np.uint64)
+    batch, m = values.shape
+    assert gamma.shape == (batch, m, 4)
+    n = m * n_bits
+    assert n & (n - 1) == 0 and gx.shape[0] >= n and hx.shape[0] >= n
+    k = n.bit_length() - 1
+    ugh_xy = np.ascontiguousarray(ugh_xy, dtype=np.uint64).reshape(24)
+    pts = np.zeros((batch, 4, 12), dtype=np.uint64)
+    sc = np.zeros((batch, 5, 4), dtype=np.uint64)
+    lr = np.zeros((batch, max(k, 1), 24), dtype=np.uint64)
+    tb, ok = C.c_double(), ci()
+    rc = hlib.bph_range_agg_prove_batch(ctx.h, curve, _p(gx), _p(gy), _p(hx), _p(hy), _p(ugh_xy), _p(values), _p(gamma), batch, m,
+                                        n_bits, seed_rand, seed_chal, reps, int(bool(host_blinders)), int(bool(verify)), _p(pts),
+                                        _p(sc), _p(lr), C.byref(tb), C.byref(ok))
+    if rc:
+        raise RuntimeError(f"bph_range_agg_prove_batch rc={rc}: {_lib.lib.bp_last_error(ctx.h).decode()}")
+    proofs = [dict(A=pts[b, 0], S=pts[b, 1], TT1=pts[b, 2], TT2=pts[b, 3], tao_x=sc[b, 0], mu=sc[b, 1], t_hat=sc[b, 2], a=sc[b, 3],
+                   b=sc[b, 4], L=lr[b, :k, :12], R=lr[b, :k, 12:], points=pts[b], scalars=sc[b], lr=lr[b]) for b in range(batch)]
+    return dict(proofs=proofs, batch_ms=tb.value, per_s=batch / tb.value * 1e3, ok=bool(ok.value))
+
+
 hlib.bph_range_agg_throughput.restype = ci
 hlib.bph_range_agg_throughput.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint64, C.c_uint64, ci, ci,
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]

@@ -259,6 +259,54 @@ int bp_range_agg_poly(bp_ctx* ctx, int curve, const uint64_t* values, size_t m, 
  * bp_range_agg_poly of this context left; n must be that call's m * n_bits (BP_E_STATE otherwise). */
 int bp_range_agg_eval(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uint64_t* l, uint64_t* r,
                       uint64_t t_hat[4]);
+/* ---- batches of aggregated range proofs -----------------------------------
+ * B proofs of one shape (m values of n_bits bits, N = m * n_bits a power of two, 2 <= N <= 4096,
+ * B <= 64) proved together: each phase of range::aggregate::prove (src/range/aggregate.rs:23-170) and
+ * each round of the inner-product argument (src/ipa/mod.rs:38-97) is ONE chain of launches whose
+ * grids serve all B proofs, so a host thread pays the launch and synchronisation latency of a
+ * proof once per batch.  Proof b's messages are those of the single-proof calls on its inputs.
+ * The base set holds gs[0..N) | hs[0..N) | u | g | h (2N + 3 points) with window tables
+ * (bp_bases_precompute).  Every array argument is B rows, row b for proof b; points come back as
+ * normalised Jacobian triples (12 u64, Z = 1, the identity as (1, 1, 0)).  The calls follow the
+ * order of the protocol: commit, poly, tcommit, eval, ipa_begin, then round_lr / round_fold until
+ * bp_range_batch_ipa_len is 1, then finish; the object can then start again at commit. */
+typedef struct bp_range_batch bp_range_batch;
+int bp_range_batch_begin(bp_ctx* ctx, const bp_bases* bases, size_t batch, size_t m, unsigned n_bits,
+                         bp_range_batch** out);
+void bp_range_batch_free(bp_range_batch* rb);
+size_t bp_range_batch_size(const bp_range_batch* rb);
+/* A_b = <a_L, gs> + <a_R, hs> + alpha_b h,  S_b = <s_L, gs> + <s_R, hs> + rho_b h
+ * (src/range/aggregate.rs:50-83).  values: B x m; alpha, rho: B scalars; out_as_xyz: B x (A, S).
+ * Blinders: s_lr = B x (s_L | s_R) (2N scalars per proof) from the caller's generator, or NULL to
+ * draw them on the device from B SplitMix64 streams -- element i of proof b is draw number
+ * first_draw + i of the stream with state seeds[b], a draw being four consecutive outputs as
+ * little-endian limbs (the generator of this library's seeded drivers; not for production
+ * secrets).  BP_E_STATE when a device draw was not below the group order (the rejection
+ * sampling of a host generator would have shifted the later draws): pass s_lr then. */
+int bp_range_batch_commit(bp_range_batch* rb, const uint64_t* values, const uint64_t* s_lr,
+                          const uint64_t* seeds, unsigned first_draw, const uint64_t* alpha,
+                          const uint64_t* rho, uint64_t* out_as_xyz);
+/* bp_range_agg_poly for every proof of the batch (src/range/aggregate.rs:88-127): y, y_inv, z:
+ * B scalars each; out_t1t2: B x (t1, t2). */
+int bp_range_batch_poly(bp_range_batch* rb, const uint64_t* y, const uint64_t* y_inv, const uint64_t* z,
+                        uint64_t* out_t1t2);
+/* T1_b = t1 g + tao1 h, T2_b = t2 g + tao2 h (src/range/aggregate.rs:126-127).  t_scalars: B x
+ * (t1, tao1, t2, tao2); out_tt_xyz: B x (T1, T2). */
+int bp_range_batch_tcommit(bp_range_batch* rb, const uint64_t* t_scalars, uint64_t* out_tt_xyz);
+/* bp_range_agg_eval for every proof (src/range/aggregate.rs:143-146): x: B scalars; out_t_hat: B
+ * scalars.  l and r stay on the device as the witnesses of the B inner-product arguments. */
+int bp_range_batch_eval(bp_range_batch* rb, const uint64_t* x, uint64_t* out_t_hat);
+/* Starts the B arguments over gs, hs' = y^-i hs, u' = u_factor_b u (src/range/aggregate.rs:148-166,
+ * src/ipa/extended.rs:15-35); u_factor: B scalars. */
+int bp_range_batch_ipa_begin(bp_range_batch* rb, const uint64_t* u_factor);
+size_t bp_range_batch_ipa_len(const bp_range_batch* rb);
+/* bp_ipa_round_lr / bp_ipa_round_fold for every proof: out_lr_xyz: B x (L, R) with the u' terms
+ * included (src/ipa/mod.rs:43-71); x, x_inv: B challenges and their inverses (:77-92). */
+int bp_range_batch_round_lr(bp_range_batch* rb, uint64_t* out_lr_xyz);
+int bp_range_batch_round_fold(bp_range_batch* rb, const uint64_t* x, const uint64_t* x_inv);
+/* the final a, b of every proof (src/ipa/mod.rs:94-97): out_ab: B x (a, b) */
+int bp_range_batch_finish(bp_range_batch* rb, uint64_t* out_ab);
+
 /* Scalars of gs_i and hs_i (i = j*n_bits + bit, n = m*n_bits = 2^k) in the single deferred MSM that
  * the checks of range::aggregate::verify_aux add up to by linearity:
  *   out_g[i] = a*s_i + z                                    (src/ipa/mod.rs:134-160; src/range/aggregate.rs:239-245)
