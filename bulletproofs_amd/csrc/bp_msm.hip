@@ -590,6 +590,138 @@ __global__ __launch_bounds__(1024) void k_small_front(
   }
 }
 
+// ---- 1-3 for batched table plans ------------------------------------------------------------
+// k_small_front gives every digit window a block of its own, and each of them converts every scalar of
+// its group again to take one digit of it.  That buys the shortest chain for ONE problem; a batch has
+// blocks enough, so here a block takes kTabFrontWindows digit windows of one group of one problem and
+// converts a scalar once for all of them: a counting pass (one histogram per window in LDS), the bucket
+// offsets, then the same walk again to place the entries.  Table plans only (8-bit digits, entries name
+// table records); the outputs are k_small_front's.
+constexpr int kTabFrontWindows = 8;
+static_assert(kTableWindowBits == 8 && kTableWindows % kTabFrontWindows == 0, "digits are the bytes of the scalar");
+constexpr u32 kTabFrontBuckets = 1u << (kTableWindowBits - 1);
+
+template <class C>
+__global__ __launch_bounds__(1024) void k_tab_front(const u32* __restrict__ s0, const uint8_t* __restrict__ inf0, size_t n0,
+                                                    const u32* __restrict__ s1, const uint8_t* __restrict__ inf1, size_t n1,
+                                                    DigitGroups sel, int group_windows, int wshift,
+                                                    u32* __restrict__ sorted_vals, u32* __restrict__ bucket_start,
+                                                    u32* __restrict__ bucket_end, u32* __restrict__ heavy_count, u32 tab_stride,
+                                                    u32 tab_off0, u32 tab_off1) {
+  using Fr = typename C::Fr;
+  __shared__ u32 hist[kTabFrontWindows * kTabFrontBuckets];
+  __shared__ u32 cursor[kTabFrontWindows * kTabFrontBuckets];
+  __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
+  const u32 sess = blockIdx.y;
+  s0 += (size_t)sess * sel.s_stride0;
+  s1 += (size_t)sess * sel.s_stride1;
+  sel.extra_s[0] += (size_t)sess * sel.extra_stride[0];
+  sel.extra_s[1] += (size_t)sess * sel.extra_stride[1];
+  const u32 parts = (u32)group_windows / kTabFrontWindows;  // blocks per group
+  const u32 g = blockIdx.x / parts, w_first = (blockIdx.x % parts) * kTabFrontWindows;
+  const u32 n_groups = gridDim.x / parts;
+  const u32 gw_first = (sess * n_groups + g) * (u32)group_windows + w_first;  // first of the block's windows among all
+  const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
+  for (u32 b = threadIdx.x; b < kTabFrontWindows * kTabFrontBuckets; b += blockDim.x) hist[b] = 0;
+  if (blockIdx.x == 0 && sess == 0 && threadIdx.x == 0) *heavy_count = 0;
+  // entry t of the group is point i of the input (see k_small_front)
+  const bool split0 = sel.half0 != 0 && sel.lo0 != sel.hi0, split1 = sel.half1 != 0 && sel.lo1 != sel.hi1;
+  size_t cnt0, cnt1;
+  {
+    const size_t q0 = split0 ? n0 / (2 * (size_t)sel.half0) : 0, r0 = split0 ? n0 % (2 * (size_t)sel.half0) : 0;
+    const size_t q1 = split1 ? n1 / (2 * (size_t)sel.half1) : 0, r1 = split1 ? n1 % (2 * (size_t)sel.half1) : 0;
+    cnt0 = !split0 ? (sel.lo0 == g ? n0 : 0)
+           : sel.hi0 == g ? q0 * sel.half0 + (r0 > sel.half0 ? r0 - sel.half0 : 0)
+           : sel.lo0 == g ? q0 * sel.half0 + (r0 < sel.half0 ? r0 : sel.half0) : 0;
+    cnt1 = !split1 ? (sel.lo1 == g ? n1 : 0)
+           : sel.hi1 == g ? q1 * sel.half1 + (r1 > sel.half1 ? r1 - sel.half1 : 0)
+           : sel.lo1 == g ? q1 * sel.half1 + (r1 < sel.half1 ? r1 : sel.half1) : 0;
+  }
+  const size_t cnt = cnt0 + cnt1 + (g < (u32)sel.n_extra ? 1 : 0);
+  __syncthreads();
+  // PLACE false: count the digits; true: write the entries at the buckets' cursors
+  auto walk = [&](auto place_tag) {
+    constexpr bool PLACE = decltype(place_tag)::value;
+#pragma unroll 1
+    for (size_t t = threadIdx.x; t < cnt; t += blockDim.x) {
+      size_t i;
+      if (t < cnt0) {
+        i = split0 ? (t / sel.half0) * 2 * (size_t)sel.half0 + t % sel.half0 + (sel.hi0 == g ? sel.half0 : 0) : t;
+      } else if (t < cnt0 + cnt1) {
+        const size_t u = t - cnt0;
+        i = n0 + (split1 ? (u / sel.half1) * 2 * (size_t)sel.half1 + u % sel.half1 + (sel.hi1 == g ? sel.half1 : 0) : u);
+      } else {
+        i = n01 + g;
+      }
+      const bool is_extra = i >= n01, second = i >= n0;
+      const u32* sp = second ? s1 + (i - n0) * 8 : s0 + i * 8;
+      if (is_extra) sp = sel.extra_s[i - n01];
+      const bool is_inf = is_extra ? false : (second ? (inf1 && inf1[i - n0]) : (inf0 && inf0[i]));
+      if (is_inf) continue;
+      Fe k = fe_from_mont<Fr>(fe_load(sp));
+      u32 flip = 0;
+      {
+        Fe nk = fe_neg<Fr>(k);
+        bool gt = false, decided = false;
+#pragma unroll
+        for (int q = 7; q >= 0; q--) {
+          if (!decided && k.v[q] != nk.v[q]) {
+            gt = k.v[q] > nk.v[q];
+            decided = true;
+          }
+        }
+        if (gt) {
+          k = nk;
+          flip = 0x80000000u;
+        }
+      }
+      const u32 j = is_extra ? sel.extra_tab[i - n01] : second ? tab_off1 + (u32)(i - n0) : tab_off0 + (u32)i;
+      // signed digits in (-128, 128] from the bytes, low to high, with the carry of the windows below
+      u32 carry = 0;
+#pragma unroll
+      for (int w = 0; w < kTableWindows; w++) {
+        const u32 v = ((k.v[w >> 2] >> (8 * (w & 3))) & 255u) + carry;
+        carry = v > kTabFrontBuckets ? 1u : 0u;
+        if ((u32)w < w_first || (u32)w >= w_first + kTabFrontWindows || (int)w >= group_windows) continue;
+        const u32 mag = carry ? 256u - v : v;
+        if (mag == 0) continue;
+        const u32 slot = ((u32)w - w_first) * kTabFrontBuckets + mag - 1;
+        if constexpr (!PLACE) {
+          atomicAdd(&hist[slot], 1u);
+        } else {
+          const u32 wid = g * (u32)group_windows + (u32)w;
+          u32 val = ((u32)w * tab_stride + j) | (wid << wshift);
+          val = (carry ? val | 0x80000000u : val) ^ flip;
+          sorted_vals[atomicAdd(&cursor[slot], 1u)] = val;
+        }
+      }
+    }
+  };
+  walk(std::false_type{});
+  __syncthreads();
+  // bucket offsets: lane t owns bucket t of the block's kTabFrontWindows x 128 (one each at 1024 lanes)
+  static_assert(kTabFrontWindows * kTabFrontBuckets == kSmallThreads, "one bucket per lane");
+  {
+    const u32 b = threadIdx.x, wl = b / kTabFrontBuckets;
+    const u32 mine = hist[b];
+    u32 total;
+    const u32 before = block_exclusive_scan(mine, wave_sums, &total);  // over all of the block's windows
+    // the entries of window wl start at its slice; those of the windows before it in this block are not in it
+    __shared__ u32 win_base[kTabFrontWindows];
+    if ((b % kTabFrontBuckets) == 0) win_base[wl] = before;
+    __syncthreads();
+    const u32 gwid = gw_first + wl;
+    const u32 st = gwid * (u32)n + (before - win_base[wl]);
+    cursor[b] = st;
+    if ((int)(w_first + wl) < group_windows) {
+      bucket_start[(size_t)gwid * kTabFrontBuckets + (b % kTabFrontBuckets)] = st;
+      bucket_end[(size_t)gwid * kTabFrontBuckets + (b % kTabFrontBuckets)] = st + mine;
+    }
+  }
+  __syncthreads();
+  walk(std::true_type{});
+}
+
 // ---- 1-3 for mid-sized problems with narrow windows ---------------------------------------
 // The same counting sort over more points than one block can hold: the points are cut into
 // slices of kMidSlice; block (slice, window) takes the digits of its slice for window w of
@@ -2089,6 +2221,111 @@ hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int
   return hipGetLastError();
 }
 
+// Window values of plans with many windows (batched plans): `lpw` lanes per window, where the kernel of
+// bp_reduce.hip puts a block of quads on every window to make ONE window's chain short.  Thousands of
+// windows fill the machine with lanes, so what counts is the additions a lane runs in a row:
+//   lane j takes buckets [j cnt, (j + 1) cnt) by running sums: run_j = their sum, acc_j = sum_k (k + 1) B_{j cnt + k};
+//   the window value is sum_j acc_j + cnt * sum_{t >= 1} Suffix_t with Suffix_t = sum_{j >= t} run_j:
+//   a scan over the lanes makes the suffixes (log2 lpw additions), log2 cnt doublings and one addition
+//   fold them into acc, and a tree adds the acc (log2 lpw additions).
+// Every lane keeps its two points in LDS and ONE inlined addition serves every step (operands are chosen by
+// address; a doubling is the addition of a point to itself): with an addition per step the body was 100 KB
+// of code against a 64 KiB instruction cache, and a lane waited for instructions more than for results.
+constexpr u32 kReduceLanesMax = 64;
+
+// point `which` (0 run, 1 acc) of lane `lane` of a block of 256: word k at (which * 32 + k) * 256 + lane, so
+// the lanes of a wave touch different banks
+BP_DEV Xyzz reduce_lds_load(const u32* pts, u32 which, u32 lane) {
+  Xyzz p;
+  const u32* b = pts + which * 32 * 256 + lane;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    p.x.v[k] = b[k * 256];
+    p.y.v[k] = b[(8 + k) * 256];
+    p.zz.v[k] = b[(16 + k) * 256];
+    p.zzz.v[k] = b[(24 + k) * 256];
+  }
+  return p;
+}
+BP_DEV void reduce_lds_store(u32* pts, u32 which, u32 lane, const Xyzz& p) {
+  u32* b = pts + which * 32 * 256 + lane;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    b[k * 256] = p.x.v[k];
+    b[(8 + k) * 256] = p.y.v[k];
+    b[(16 + k) * 256] = p.zz.v[k];
+    b[(24 + k) * 256] = p.zzz.v[k];
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void k_window_reduce_lanes(const u32* __restrict__ buckets, size_t nbt, u32 n_buckets,
+                                                             int log_lpw, int log_cnt, u32 n_windows,
+                                                             u32* __restrict__ windows) {
+  using F = typename C::Fq;
+  __shared__ u32 pts[2 * 32 * 256];  // per lane: run, acc
+  const u32 tid = threadIdx.x, lpw = 1u << log_lpw, cnt = 1u << log_cnt;
+  const u32 t = blockIdx.x * blockDim.x + tid;
+  const u32 w = t >> log_lpw, j = t & (lpw - 1);
+  const bool live = w < n_windows;  // whole lane groups (parts of one wave) are live or not
+  constexpr u32 RUN = 0, ACC = 1, NONE = 2;
+  {
+    const Xyzz id = xyzz_identity<F>();
+    reduce_lds_store(pts, RUN, tid, id);
+    reduce_lds_store(pts, ACC, tid, id);
+  }
+  quad_sync();
+  const size_t base = (size_t)w * n_buckets + (size_t)j * cnt;
+  const int local_steps = 2 * (int)cnt, scan_end = local_steps + log_lpw, dbl_end = scan_end + log_cnt;
+  const int total = dbl_end + 1 + log_lpw;
+#pragma unroll 1
+  for (int step = 0; step < total; step++) {
+    // dst += src: points named by (which, lane); src NONE with from_bucket: a bucket sum from memory
+    u32 dst = NONE, src = NONE, src_lane = tid;
+    bool from_bucket = false;
+    size_t bucket = 0;
+    if (step < local_steps) {
+      if ((step & 1) == 0) {
+        dst = RUN;
+        from_bucket = true;
+        bucket = base + (size_t)(cnt - 1 - (u32)(step >> 1));
+      } else {
+        dst = ACC;
+        src = RUN;
+      }
+    } else if (step < scan_end) {
+      const u32 d = 1u << (step - local_steps);
+      if (j + d < lpw) {
+        dst = RUN;
+        src = RUN;
+        src_lane = tid + d;
+      }
+    } else if (step < dbl_end) {
+      if (j >= 1) dst = src = RUN;
+    } else if (step == dbl_end) {
+      if (j >= 1) {
+        dst = ACC;
+        src = RUN;
+      }
+    } else {
+      const u32 d = lpw >> (step - dbl_end);
+      if (j < d) {
+        dst = src = ACC;
+        src_lane = tid + d;
+      }
+    }
+    if (live && dst != NONE) {
+      Xyzz p = reduce_lds_load(pts, dst, tid);
+      const Xyzz q = from_bucket ? xyzz_load_soa(buckets, nbt, bucket) : reduce_lds_load(pts, src, src_lane);
+      xyzz_add<F>(p, q);
+      quad_sync();  // every lane of the wave has read its operands
+      reduce_lds_store(pts, dst, tid, p);
+    }
+    quad_sync();
+  }
+  if (live && j == 0) xyzz_store_aos(windows + (size_t)w * 32, xyzz_export<C>(reduce_lds_load(pts, ACC, tid)));
+}
+
 // one wave per sum: lane l < count holds point l, a shuffle tree joins them (count <= 64)
 template <class C>
 __global__ __launch_bounds__(64) void k_window_group_sums(const u32* __restrict__ in, int count, u32* __restrict__ out) {
@@ -2160,6 +2397,17 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
   if (plan.small) {
     sel.s_stride0 = (u32)p0.batch_stride;
     sel.s_stride1 = (u32)p1.batch_stride;
+    static const bool no_tab_front = getenv("BP_MSM_NO_TAB_FRONT") != nullptr;
+    if (plan.batch > 1 && plan.tab_virtual && plan.group_windows % kTabFrontWindows == 0 && !no_tab_front) {
+      // a batch has blocks enough for each to take several digit windows and convert a scalar once for them
+      const unsigned parts = (unsigned)(plan.group_windows / kTabFrontWindows);
+      DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_tab_front<C>, dim3(parts * (unsigned)plan.groups, (unsigned)plan.batch),
+                                               dim3(kSmallThreads), 0, st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, sel,
+                                               plan.group_windows, plan.wshift, ws.vals_b, ws.bucket_start, ws.bucket_end,
+                                               ws.heavy_count, (u32)table->stride, (u32)p0.tab_offset, (u32)p1.tab_offset));
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1, table->rec);
+    }
     // sorted entries and bucket bounds straight into the buffers the accumulation reads
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_small_front<C>, dim3((unsigned)(plan.n_windows / plan.batch), (unsigned)plan.batch),
                                              dim3(kSmallThreads), 0, st,
@@ -2444,6 +2692,20 @@ static hipError_t msm_reduce(int curve, const MsmPlan& plan, const MsmWorkspace&
   const size_t nbt = (size_t)plan.n_windows * plan.n_buckets;
   // four lanes per point addition (bp_reduce.hip) unless BP_MSM_REDUCE_SERIAL asks for one
   static const bool serial_reduce = getenv("BP_MSM_REDUCE_SERIAL") != nullptr;
+  // many windows (batched plans): lanes that each run a short chain fill the machine; a block of quads per
+  // window would leave most of it waiting for 4096 chains made as short as one can be
+  static const int lanes_from = getenv("BP_MSM_REDUCE_LANES_FROM") ? atoi(getenv("BP_MSM_REDUCE_LANES_FROM")) : 512;
+  static const int lanes_log = getenv("BP_MSM_REDUCE_LPW_LOG") ? atoi(getenv("BP_MSM_REDUCE_LPW_LOG")) : 4;
+  if (plan.n_windows >= lanes_from && plan.n_buckets >= 2 * kReduceLanesMax && plan.n_buckets <= 256) {
+    int log_nb = 0;
+    while ((1u << log_nb) < plan.n_buckets) log_nb++;
+    const int log_lpw = lanes_log >= 1 && lanes_log <= 6 ? lanes_log : 4;
+    const size_t threads = (size_t)plan.n_windows << log_lpw;
+    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_window_reduce_lanes<C>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                                             ws.buckets, nbt, plan.n_buckets, log_lpw, log_nb - log_lpw, (u32)plan.n_windows,
+                                             ws.windows));
+    return hipGetLastError();
+  }
   if (plan.n_buckets >= 64 && plan.n_buckets <= 256) {
     if (!serial_reduce)
       return launch_window_reduce_quad(curve, ws.buckets, nbt, plan.n_buckets, plan.n_windows, ws.windows, st);

@@ -193,6 +193,7 @@ struct RangeAggregate {
     const size_t B = bp_range_batch_size(rb), n = (size_t)n_bits * m;
     if (n != crs.n || B == 0) throw std::invalid_argument("CRS registered for another size");
     std::vector<RangeProof> prs(B);
+    PhaseTrace tr;
     std::vector<Scalar> alpha(B), rho(B);
     for (size_t b = 0; b < B; b++) { alpha[b] = rngs[b]->scalar(); rho[b] = rngs[b]->scalar(); }   // :66-67
     std::vector<Projective> pts(2 * B);
@@ -213,6 +214,7 @@ struct RangeAggregate {
       }
       check(ctx, rc, "bp_range_batch_commit");                                                     // :80-83
     }
+    tr.mark("batch: A, S");
     std::vector<Scalar> y(B), z(B), y_inv;
     for (size_t b = 0; b < B; b++) {
       prs[b].a = pts[2 * b]; prs[b].s = pts[2 * b + 1];
@@ -222,11 +224,13 @@ struct RangeAggregate {
     S::batch_inv(y, y_inv);
     std::vector<Scalar> t12(2 * B), tsc(4 * B);
     check(ctx, bp_range_batch_poly(rb, y[0].l, y_inv[0].l, z[0].l, t12[0].l), "bp_range_batch_poly");  // :88-120
+    tr.mark("batch: transcript, polynomials");
     for (size_t b = 0; b < B; b++) {
       tsc[4 * b] = t12[2 * b]; tsc[4 * b + 1] = rngs[b]->scalar();                                 // :121-122
       tsc[4 * b + 2] = t12[2 * b + 1]; tsc[4 * b + 3] = rngs[b]->scalar();
     }
     check(ctx, bp_range_batch_tcommit(rb, tsc[0].l, pts[0].xyz), "bp_range_batch_tcommit");        // :126-127
+    tr.mark("batch: T1, T2");
     std::vector<Scalar> x(B), xi;
     for (size_t b = 0; b < B; b++) {
       prs[b].tt1 = pts[2 * b]; prs[b].tt2 = pts[2 * b + 1];
@@ -246,8 +250,10 @@ struct RangeAggregate {
       xe[b] = ts[b]->verifier_scalar();                                                            // src/ipa/extended.rs:22
     }
     check(ctx, bp_range_batch_ipa_begin(rb, xe[0].l), "bp_range_batch_ipa_begin");                 // :148-166
+    tr.mark("batch: transcript, eval");
     while (bp_range_batch_ipa_len(rb) != 1) {
       check(ctx, bp_range_batch_round_lr(rb, pts[0].xyz), "bp_range_batch_round_lr");              // src/ipa/mod.rs:43-71
+      tr.mark("batch: round L, R");
       for (size_t b = 0; b < B; b++) {
         ts[b]->prover_points(&pts[2 * b], 2);                                                      // :75
         x[b] = ts[b]->verifier_scalar();                                                           // :77
@@ -255,6 +261,7 @@ struct RangeAggregate {
       }
       S::batch_inv(x, xi);                                                                         // :78
       check(ctx, bp_range_batch_round_fold(rb, x[0].l, xi[0].l), "bp_range_batch_round_fold");     // :80-92
+      tr.mark("batch: transcript, fold");
     }
     check(ctx, bp_range_batch_finish(rb, t12[0].l), "bp_range_batch_finish");
     for (size_t b = 0; b < B; b++) {
