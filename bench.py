@@ -360,9 +360,21 @@ def range_proofs(ctx, device, workers=8, per_worker=8, cpu=True, extras=True):
                                                  per_worker, seed, seed + 1)
     if not (one["ok"] and thr["ok"]):
         raise SystemExit("aggregated range proof failed to verify")
+    # 64 proofs over different values through shared launches from ONE host thread (bp_range_batch_*); every proof
+    # of the first batch is verified
+    rng = np.random.default_rng(seed + 8)
+    pvals = rng.integers(0, 1 << 64, (64, 64), dtype=np.uint64)
+    pgam = rng.integers(0, 1 << 64, (64, 64, 4), dtype=np.uint64)
+    pgam[:, :, 3] &= np.uint64((1 << 63) - 1)
+    pb = host_mirror.range_aggregate_prove_batch(ctx, bp.SECP256K1, gs, hs, ugh, pvals, pgam, 64, seed, seed + 1, reps=1, verify=True)
+    if not pb["ok"]:
+        raise SystemExit("a proof of the batch of 64 failed to verify")
+    pb = host_mirror.range_aggregate_prove_batch(ctx, bp.SECP256K1, gs, hs, ugh, pvals, pgam, 64, seed, seed + 1, reps=5)
+    batched = {"workload": "64 proofs of 64 x 64 bits proved together, one host thread, one context", "batch_ms": pb["batch_ms"],
+               "prove_per_s": pb["per_s"]}
     if not extras:  # the figures that are summed over the GPUs of a node
         return {"workload": "m = 64 values x 64 bits (N = 4096), secp256k1, prove and verify, 1 GPU", "prove_per_s": thr["prove_per_s"],
-                "verify_per_s": thr["verify_per_s"], "host_threads": workers,
+                "verify_per_s": thr["verify_per_s"], "host_threads": workers, "prove_batch_64": batched,
                 "one_at_a_time": {"prove_ms": one["prove_ms"], "verify_ms": one["verify_ms"]}}
     g1, h1 = tuple(None if v is None else v[:64] for v in gs), tuple(None if v is None else v[:64] for v in hs)
     host_mirror.range_aggregate_roundtrip(ctx, bp.SECP256K1, g1, h1, ugh, values[:1], gamma[:1], 64, seed, seed + 1, reps=1,
@@ -377,6 +389,7 @@ def range_proofs(ctx, device, workers=8, per_worker=8, cpu=True, extras=True):
         "prove_per_s": thr["prove_per_s"],
         "verify_per_s": thr["verify_per_s"],
         "host_threads": workers,
+        "prove_batch_64": batched,
         "one_at_a_time": {"prove_ms": one["prove_ms"], "verify_ms": one["verify_ms"]},
         "note": "host threads with one context each on the same GPU; every proof verified; transcript is a seeded "
                 "stand-in for the reference's Fiat-Shamir sponge",
@@ -521,6 +534,24 @@ def msm_in_flight(bp, device, dx, dy, dk, n, steps, workers=2):
     dt = time.perf_counter() - t0
     return {"value": workers * steps * n / dt, "unit": "points/s", "workers": workers, "steps_each": steps,
             "ms_per_msm": dt / (workers * steps) * 1e3}
+
+
+def msm_sizes(ctx, bp, dx, dy, dk, n_max, steps):
+    """the five sizes of benches/msm_bench.rs (2^16 .. 2^20 points) on prefixes of the headline inputs: wall time per
+    MSM over `steps` calls after a warm-up, inputs resident in HBM"""
+    out = {}
+    for lg in range(16, 21):
+        n = 1 << lg
+        if n > n_max:
+            break
+        for _ in range(3):
+            ctx.msm_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.msm_dev(bp.SECP256K1, dx.data_ptr(), dy.data_ptr(), None, dk.data_ptr(), n)
+        dt = (time.perf_counter() - t0) / steps
+        out[f"2^{lg}"] = {"ms": dt * 1e3, "points_per_s": n / dt, "device_phase_ms": ctx.last_kernel_ms(1)}
+    return out
 
 
 def main():
@@ -678,6 +709,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n)
         if not args.no_range and world == 1:
             out["range_proofs"] = range_proofs(ctx, local_rank, cpu=not args.no_cpu_baseline)
+        if world == 1:
+            out["msm_sizes"] = msm_sizes(ctx, bp, dx, dy, dk, n, args.steps)
         if world == 1 and not args.no_in_flight:
             out["msm_two_in_flight"] = msm_in_flight(bp, local_rank, dx, dy, dk, n, args.steps)
         if world == 1 and not args.no_streaming:

@@ -1785,6 +1785,77 @@ int ipa_begin_common(bp_ctx* ctx, int curve, int variant, const bp_bases* res, s
   return BP_OK;
 }
 
+// The step lists of launch_ipa_rebase_tab for one generator set: `coef` = the m shared coefficients
+// (Montgomery form); lists for 2^log_s lanes, each `*len` steps long (padded), appended to `out`.
+// The signed 8-bit digits of the coefficients are sorted by size, largest first, and dealt out in equal
+// runs.  A lane walks its run as a bucket reduction walks buckets: run += record; total += run once per
+// digit value passed; what is left below its smallest digit c, (c - 1) * run, is made by double-and-add
+// in tmp and added to total.
+bool rebase_tab_program(int curve, const uint64_t* coef, size_t m, int log_s, std::vector<u32>& out, int* len) {
+  struct Entry { u32 mag, neg, w, t; };
+  std::vector<Entry> entries;
+  entries.reserve(m * kTableWindows);
+  for (size_t t = 0; t < m; t++) {
+    host::HFe c;
+    memcpy(c.v, coef + 4 * t, 32);
+    c = curve == BP_SECP256K1 ? host::h_from_mont<Secp256k1Fr>(c) : host::h_from_mont<VestaFr>(c);
+    const host::HFe nc = curve == BP_SECP256K1 ? host::h_neg<Secp256k1Fr>(c) : host::h_neg<VestaFr>(c);  // r - c on the canonical value
+    u32 flip = 0;
+    // the smaller of c and r - c
+    for (int q = 3; q >= 0; q--) {
+      if (c.v[q] != nc.v[q]) {
+        if (c.v[q] > nc.v[q]) { c = nc; flip = 1; }
+        break;
+      }
+    }
+    u32 carry = 0;
+    for (int w = 0; w < kTableWindows; w++) {
+      const u32 v = (u32)((c.v[w >> 3] >> (8 * (w & 7))) & 255u) + carry;
+      carry = v > 128u ? 1u : 0u;
+      const u32 mag = carry ? 256u - v : v;
+      if (mag) entries.push_back(Entry{mag, carry ^ flip, (u32)w, (u32)t});
+    }
+    if (carry) return false;  // cannot happen: the value is below 2^255
+  }
+  std::stable_sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.mag > b.mag; });
+  const size_t lanes = (size_t)1 << log_s, per = (entries.size() + lanes - 1) / lanes;
+  enum : u32 { RUN = 0, TOTAL = 1, TMP = 2, TABLE = 3 };
+  auto step = [](u32 dst, u32 src) { return dst << 30 | src << 28; };
+  std::vector<std::vector<u32>> lists(lanes);
+  size_t longest = 1;
+  for (size_t s = 0; s < lanes; s++) {
+    std::vector<u32>& l = lists[s];
+    const size_t b = std::min(entries.size(), s * per), e = std::min(entries.size(), b + per);
+    if (b < e) {
+      u32 cur = entries[b].mag;
+      for (size_t k = b; k < e; k++) {
+        for (; cur > entries[k].mag; cur--) l.push_back(step(TOTAL, RUN));
+        l.push_back(step(RUN, TABLE) | entries[k].neg << 27 | entries[k].w << 22 | entries[k].t);
+      }
+      l.push_back(step(TOTAL, RUN));
+      const u32 rest = cur - 1;  // the digit values below the run's smallest: total += rest * run
+      if (rest) {
+        l.push_back(step(TMP, RUN));
+        int top = 31;
+        while (!((rest >> top) & 1u)) top--;
+        for (int bit = top - 1; bit >= 0; bit--) {
+          l.push_back(step(TMP, TMP));
+          if ((rest >> bit) & 1u) l.push_back(step(TMP, RUN));
+        }
+        l.push_back(step(TOTAL, TMP));
+      }
+    }
+    longest = std::max(longest, l.size());
+  }
+  if (longest * lanes > kRebaseTabProgMax) return false;
+  for (size_t s = 0; s < lanes; s++) {
+    lists[s].resize(longest, kRebaseTabNop);
+    out.insert(out.end(), lists[s].begin(), lists[s].end());
+  }
+  *len = (int)longest;
+  return true;
+}
+
 // Replaces the session's generators by the folded ones of the current length n (see
 // launch_ipa_rebase): from here on the rounds run over n (2n with H) points instead of n0 each, the
 // coefficients start again at one and the fold history is empty.  Only for sessions whose H
@@ -1807,6 +1878,58 @@ int ipa_rebase(bp_ipa* s) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(coef.data(), ctx->pinned, (size_t)sets * m * 32);
   }
+  // new planes: x | y per set, then the infinity flags
+  const size_t plane = (n * 32 + 255) & ~(size_t)255;
+  void* blk = nullptr;
+  HIPCHK(ctx, hipMalloc(&blk, (size_t)sets * (2 * plane + ((n + 255) & ~(size_t)255))));
+  char* base = (char*)blk;
+  u32* ngx = (u32*)base;
+  u32* ngy = (u32*)(base + plane);
+  u32* nhx = (u32*)(base + 2 * plane);
+  u32* nhy = (u32*)(base + 3 * plane);
+  uint8_t* ngi = (uint8_t*)(base + (size_t)sets * 2 * plane);
+  uint8_t* nhi = ngi + ((n + 255) & ~(size_t)255);
+  hipError_t e = hipErrorUnknown;
+  bool launched = false;
+  static const bool no_tab_rebase = getenv("BP_IPA_REBASE_NO_TAB") != nullptr;
+  if (s->res && s->res->tab && !no_tab_rebase) {
+    // the generators are those of a base set with window tables: the folded ones are sums of small multiples
+    // of table records.  Lanes per output: as many as fill the machine about once.
+    int log_s = 0;
+    while (log_s < kRebaseTabMaxLogS && ((n * (size_t)sets) << (log_s + 1)) <= 65536) log_s++;
+    if (const char* ev = getenv("BP_IPA_REBASE_LOG_S")) log_s = std::min(kRebaseTabMaxLogS, std::max(0, atoi(ev)));
+    std::vector<u32> prog;
+    int len[2] = {0, 0};
+    bool ok = true;
+    for (int k = 0; k < sets && ok; k++)
+      ok = rebase_tab_program(s->curve, &coef[(size_t)k * m * 4], m, log_s, prog, &len[k]);
+    if (ok && sets == 2 && len[0] != len[1]) {
+      // one launch serves both sets: the shorter lists are padded to the longer
+      const int longest = std::max(len[0], len[1]);
+      std::vector<u32> padded;
+      size_t at = 0;
+      for (int k = 0; k < 2; k++)
+        for (size_t lane = 0; lane < ((size_t)1 << log_s); lane++) {
+          padded.insert(padded.end(), prog.begin() + at, prog.begin() + at + len[k]);
+          padded.resize(padded.size() + (size_t)(longest - len[k]), kRebaseTabNop);
+          at += (size_t)len[k];
+        }
+      prog.swap(padded);
+      len[0] = len[1] = longest;
+      ok = ((size_t)longest << log_s) <= kRebaseTabProgMax;
+    }
+    if (ok) {
+      void* d_prog;
+      int rc = upload(ctx, S_IN5, prog.data(), prog.size() * sizeof(u32), &d_prog);
+      if (rc != BP_OK) { (void)hipFree(blk); return rc; }
+      const size_t per_set = (size_t)len[0] << log_s;
+      RebaseTabSet ts[2] = {{(u32)s->g_off, s->res->inf, (const u32*)d_prog, ngx, ngy, ngi},
+                            {(u32)s->h_off, s->res->inf, (const u32*)d_prog + per_set, nhx, nhy, nhi}};
+      e = launch_ipa_rebase_tab(s->curve, s->res->tab, s->res->n, ts, sets, n, log_s, len[0], ctx->stream);
+      launched = true;
+    }
+  }
+  if (!launched) {
   // signed 3-bit digits of the canonical values: v = sum_w d_w 8^w, d_w in [-4, 4]
   std::vector<int8_t> digits((size_t)sets * m * kRebaseWindows);
   for (size_t r = 0; r < (size_t)sets * m; r++) {
@@ -1830,26 +1953,17 @@ int ipa_rebase(bp_ipa* s) {
         carry = 0;
       }
     }
-    if (carry) return fail(ctx, BP_E_STATE, "ipa_rebase: digit overflow");  // cannot happen below 2^256
+    if (carry) { (void)hipFree(blk); return fail(ctx, BP_E_STATE, "ipa_rebase: digit overflow"); }  // cannot happen below 2^256
   }
   void *d_digits, *tmp;
-  CHK(upload(ctx, S_IN5, digits.data(), digits.size(), &d_digits));
-  CHK(reserve(ctx, S_REBASE, (size_t)sets * n * kRebaseWindows * 128, &tmp));
-  // new planes: x | y per set, then the infinity flags
-  const size_t plane = (n * 32 + 255) & ~(size_t)255;
-  void* blk = nullptr;
-  HIPCHK(ctx, hipMalloc(&blk, (size_t)sets * (2 * plane + ((n + 255) & ~(size_t)255))));
-  char* base = (char*)blk;
-  u32* ngx = (u32*)base;
-  u32* ngy = (u32*)(base + plane);
-  u32* nhx = (u32*)(base + 2 * plane);
-  u32* nhy = (u32*)(base + 3 * plane);
-  uint8_t* ngi = (uint8_t*)(base + (size_t)sets * 2 * plane);
-  uint8_t* nhi = ngi + ((n + 255) & ~(size_t)255);
+  int rc = upload(ctx, S_IN5, digits.data(), digits.size(), &d_digits);
+  if (rc == BP_OK) rc = reserve(ctx, S_REBASE, (size_t)sets * n * kRebaseWindows * 128, &tmp);
+  if (rc != BP_OK) { (void)hipFree(blk); return rc; }
   RebaseSet rs[2] = {
       {s->gx, s->gy, s->ginf, (const int8_t*)d_digits, (u32*)tmp, ngx, ngy, ngi},
       {s->hx, s->hy, s->hinf, (const int8_t*)d_digits + m * kRebaseWindows, (u32*)tmp + n * kRebaseWindows * 32, nhx, nhy, nhi}};
-  hipError_t e = launch_ipa_rebase(s->curve, rs, sets, n, m, ctx->stream);
+  e = launch_ipa_rebase(s->curve, rs, sets, n, m, ctx->stream);
+  }
   if (e == hipSuccess) e = launch_fill_one(s->curve, s->cg, n, ctx->stream);
   if (e == hipSuccess && has_h) e = launch_fill_one(s->curve, s->ch, n, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

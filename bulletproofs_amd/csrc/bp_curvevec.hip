@@ -400,6 +400,133 @@ hipError_t launch_ipa_rebase(int curve, const RebaseSet* sets, int n_sets, size_
   return hipGetLastError();
 }
 
+// ---- folded generators from window tables ------------------------------------------------------
+struct RebaseTabJob {
+  const u32* table;
+  size_t stride;
+  RebaseTabSet set[2];
+};
+
+constexpr u32 kRebaseTabThreads = 128;
+
+// point `which` of lane `lane` of a block: word k at (which * 32 + k) * kRebaseTabThreads + lane
+BP_DEV Xyzz rebase_lds_load(const u32* pts, u32 which, u32 lane) {
+  Xyzz p;
+  const u32* b = pts + which * 32 * kRebaseTabThreads + lane;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    p.x.v[k] = b[k * kRebaseTabThreads];
+    p.y.v[k] = b[(8 + k) * kRebaseTabThreads];
+    p.zz.v[k] = b[(16 + k) * kRebaseTabThreads];
+    p.zzz.v[k] = b[(24 + k) * kRebaseTabThreads];
+  }
+  return p;
+}
+BP_DEV void rebase_lds_store(u32* pts, u32 which, u32 lane, const Xyzz& p) {
+  u32* b = pts + which * 32 * kRebaseTabThreads + lane;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    b[k * kRebaseTabThreads] = p.x.v[k];
+    b[(8 + k) * kRebaseTabThreads] = p.y.v[k];
+    b[(16 + k) * kRebaseTabThreads] = p.zz.v[k];
+    b[(24 + k) * kRebaseTabThreads] = p.zzz.v[k];
+  }
+}
+
+// UNIFY: a table record is added as a full point, so that lanes of a wave which run different lists
+// (log_s > 0) still run one instruction stream; without it (one list for all lanes) a record is a mixed
+// addition and the choice between the two additions a uniform branch
+template <class C, bool UNIFY>
+__global__ __launch_bounds__(kRebaseTabThreads) void k_rebase_tab(RebaseTabJob job, size_t n, int log_s, int len) {
+  using P = typename C::Pipeline;
+  using F = typename P::Fq;
+  __shared__ u32 pts[3 * 32 * kRebaseTabThreads];
+  __shared__ u32 prog[kRebaseTabProgMax];
+  const RebaseTabSet& set = job.set[blockIdx.y];
+  const u32 tid = threadIdx.x, lanes = 1u << log_s;
+  for (u32 k = tid; k < lanes * (u32)len; k += kRebaseTabThreads) prog[k] = set.prog[k];
+  {
+    const Xyzz id = xyzz_identity<F>();
+    for (u32 which = 0; which < 3; which++) rebase_lds_store(pts, which, tid, id);
+  }
+  __syncthreads();
+  const size_t g = (size_t)blockIdx.x * kRebaseTabThreads + tid;
+  const size_t i = g >> log_s;
+  const u32 s = (u32)g & (lanes - 1);
+  const bool live = i < n;  // the lanes of an output are live together
+  const u32* __restrict__ table = job.table;
+#pragma unroll 1
+  for (int slot = 0; slot < len; slot++) {
+    const u32 op = prog[s * (u32)len + (u32)slot];
+    const u32 dst = op >> 30, src = (op >> 28) & 3u;
+    if (!live || dst == 3u) continue;
+    Xyzz p = rebase_lds_load(pts, dst, tid);
+    Xyzz q = xyzz_identity<F>();
+    bool mixed = false;
+    Fe x = fe_zero(), y = fe_zero();
+    if (src == 3u) {
+      const size_t j = (size_t)set.off + i + n * (size_t)(op & 0x3FFFFFu);
+      if (!(set.inf && set.inf[j])) {
+        const u32* rec = table + ((size_t)((op >> 22) & 31u) * job.stride + j) * 16;
+        x = fe_load(rec);
+        y = fe_load(rec + 8);
+        if ((op >> 27) & 1u) y = fe_neg<F>(y);
+        if constexpr (UNIFY) {
+          q = xyzz_from_affine<F>(x, y);
+        } else {
+          mixed = true;
+        }
+      }
+    } else {
+      q = rebase_lds_load(pts, src, tid);
+    }
+    // one addition for every kind of step when the lanes of a wave run different lists
+    if (mixed)
+      xyzz_madd<F>(p, x, y);
+    else
+      xyzz_add<F>(p, q);
+    rebase_lds_store(pts, dst, tid, p);
+  }
+  // the lanes of an output sit side by side in one wave: their totals are added by a tree
+  for (u32 d = lanes >> 1; d > 0; d >>= 1) {
+    quad_sync();
+    if (live && s < d) {
+      Xyzz p = rebase_lds_load(pts, 1, tid);
+      const Xyzz q = rebase_lds_load(pts, 1, tid + d);
+      xyzz_add<F>(p, q);
+      quad_sync();
+      rebase_lds_store(pts, 1, tid, p);
+    }
+  }
+  if (live && s == 0) {
+    const Xyzz v = rebase_lds_load(pts, 1, tid);
+    Fe x, y;
+    const bool inf = xyzz_to_affine<F>(v, x, y);
+    fe_store(set.ox + i * 8, inf ? x : fe_export<P>(x));
+    fe_store(set.oy + i * 8, inf ? y : fe_export<P>(y));
+    set.oinf[i] = inf ? 1 : 0;
+  }
+}
+
+hipError_t launch_ipa_rebase_tab(int curve, const u32* table, size_t stride, const RebaseTabSet* sets, int n_sets, size_t n,
+                                 int log_s, int len, hipStream_t st) {
+  if (!table || n == 0 || n_sets < 1 || n_sets > 2 || log_s < 0 || log_s > kRebaseTabMaxLogS || len < 1 ||
+      ((size_t)len << log_s) > kRebaseTabProgMax)
+    return hipErrorInvalidValue;
+  RebaseTabJob job{};
+  job.table = table;
+  job.stride = stride;
+  for (int k = 0; k < n_sets; k++) job.set[k] = sets[k];
+  const unsigned bx = (unsigned)((((size_t)n << log_s) + kRebaseTabThreads - 1) / kRebaseTabThreads);
+  DISPATCH_CURVE(curve, {
+    if (log_s > 0)
+      hipLaunchKernelGGL((k_rebase_tab<C, true>), dim3(bx, (unsigned)n_sets), dim3(kRebaseTabThreads), 0, st, job, n, log_s, len);
+    else
+      hipLaunchKernelGGL((k_rebase_tab<C, false>), dim3(bx, (unsigned)n_sets), dim3(kRebaseTabThreads), 0, st, job, n, log_s, len);
+  });
+  return hipGetLastError();
+}
+
 // dst[r] = src[r * stride_elems] (field elements): one column of a matrix of scalars
 __global__ __launch_bounds__(256) void k_gather_column(const u32* __restrict__ src, size_t stride_elems, size_t count,
                                                        u32* __restrict__ dst) {

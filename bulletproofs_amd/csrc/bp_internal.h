@@ -127,6 +127,28 @@ struct RebaseSet {
 };
 hipError_t launch_ipa_rebase(int curve, const RebaseSet* sets, int n_sets, size_t n, size_t m, hipStream_t st);
 hipError_t launch_gather_column(const u32* src, size_t stride_elems, size_t count, u32* dst, hipStream_t st);
+// The same folded generators from the window tables of a registered base set (launch_window_tables:
+// record (w, j) = 2^(8 w) * P_j): G'_i = sum over the non-zero signed 8-bit digits d of the m shared
+// coefficients s_t of d * T[w][off + i + n t], a sum of small multiples of known points.  Output i is
+// made by 2^log_s adjacent lanes, each running its own list of `len` steps "point += point" over three
+// points it keeps (run, total, tmp) and the table records (rebase_tab_program builds the lists: entries
+// sorted by digit size, run/total as in a bucket reduction, the rest of a lane's weight by double-and-add);
+// the lanes' totals are added and normalised.  Steps are u32 words:
+//   dst << 30 | src << 28 | neg << 27 | w << 22 | t     dst, src: 0 run, 1 total, 2 tmp; src 3: table record
+//   (w, t), negated if neg; dst 3: no operation
+constexpr u32 kRebaseTabNop = 0xFFFFFFFFu;
+constexpr size_t kRebaseTabProgMax = 4096;  // words of all lists of one set together (2^log_s * len)
+constexpr int kRebaseTabMaxLogS = 4;
+struct RebaseTabSet {
+  u32 off;             // index of the set's first generator in the base set
+  const uint8_t* inf;  // identity flags of the base set's points, may be null
+  const u32* prog;     // 2^log_s lists of len steps, device memory
+  u32* ox;
+  u32* oy;
+  uint8_t* oinf;
+};
+hipError_t launch_ipa_rebase_tab(int curve, const u32* table, size_t stride, const RebaseTabSet* sets, int n_sets, size_t n,
+                                 int log_s, int len, hipStream_t st);
 // n records of 72 bytes {x, y, infinity byte, padding} -> planes
 hipError_t launch_aos_split(const u32* aos, size_t n, u32* x, u32* y, uint8_t* inf, hipStream_t st);
 

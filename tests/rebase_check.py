@@ -1,7 +1,8 @@
 """Run by test_gpu_rebase.py in a process of its own (the thresholds are read once per process):
 an inner-product argument whose session replaces its generators by the folded ones every two
 rounds, checked round by round against the Python oracle, with reads of the folded generators in
-between and at the end.  usage: BP_IPA_REBASE_MIN=16 BP_IPA_REBASE_M=4 python tests/rebase_check.py"""
+between and at the end; once with the generators handed over with the call and once over a registered
+base set with window tables (whose first replacement reads the tables).  usage: BP_IPA_REBASE_MIN=16 BP_IPA_REBASE_M=4 python tests/rebase_check.py"""
 import os
 import sys
 
@@ -18,14 +19,21 @@ from util import xyz_to_affine  # noqa: E402
 
 ctx = bp.Context(0)
 n, k = 128, 7
-for c in (o.SECP256K1, o.VESTA):
-    for variant in (0, 1):
+for c, variant, resident in [(c, v, r) for c in (o.SECP256K1, o.VESTA) for v in (0, 1) for r in (False, True)]:
+    if True:
         g, h, a, b, ch = ipa_inputs(c, n, 991 + variant + 7 * c.id)
         while len(ch) < k:
             ch.append((ch[-1] * 7 + 3) % c.n)
         g[5] = None  # an identity among the generators
-        s = ctx.ipa_begin(c.id, variant, o.pack_points(g, c), o.pack_points(h, c) if variant == 0 else None,
-                          o.pack_field(a, c.n), o.pack_field(b, c.n))
+        bases = None
+        if resident:
+            both = o.pack_points(g + h, c)
+            bases = ctx.register_bases(c.id, both)
+            bases.precompute()
+            s = ctx.ipa_begin_resident(bases, variant, 0, n, o.pack_field(a, c.n), o.pack_field(b, c.n))
+        else:
+            s = ctx.ipa_begin(c.id, variant, o.pack_points(g, c), o.pack_points(h, c) if variant == 0 else None,
+                              o.pack_field(a, c.n), o.pack_field(b, c.n))
         gs, hs, av, bv = list(g), list(h), list(a), list(b)
         for j in range(k):
             L, R, cl, cr = s.round_lr()
@@ -46,5 +54,7 @@ for c in (o.SECP256K1, o.VESTA):
         if variant == 0:
             assert o.unpack_points(*H, c) == hs
         s.free()
-        print("ok", c.name, variant, flush=True)
+        if bases is not None:
+            bases.free()
+        print("ok", c.name, variant, "resident" if resident else "direct", flush=True)
 print("rebase check passed")
