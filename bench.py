@@ -229,6 +229,16 @@ def other_configs(ctx, px, py, cpu=True):
         out["poly_commit_2_20"] = {"workload": "polynomial commitment opening, degree 2^20 - 1, CRS resident",
                                    "prove_ms": res["prove_ms"], "verify_ms": res["verify_ms"],
                                    "all_verified": bool(res["verify_ok"] and res["lazy_ok"] and res["halo_ok"])}
+        # 16 openings checked together: two distinct openings cycled through the batch, the MSM over the 2^20
+        # generators once for all of them (PolyCommit::verify_batch), against the same 16 verified one by one
+        vb = host_mirror.poly_commit_verify_batch(ctx, C, gs, hg, np.stack([coeffs, np.ascontiguousarray(coeffs[::-1])]),
+                                                  np.stack([r[0], r[0]]), np.stack([x[0], x[0]]), batch=16, seed_rand=SEED,
+                                                  seed_chal=SEED + 1, reps=3)
+        if not (vb["ok_batch"] and vb["ok_each"]):
+            raise SystemExit("batch of polynomial-commitment openings at degree 2^20 - 1 failed to verify")
+        out["poly_commit_2_20"]["verify_batch_16"] = {"workload": "16 openings of degree 2^20 - 1 verified together, CRS resident",
+                                                      "ms": vb["batch_ms"], "openings_per_s": 16.0 / vb["batch_ms"] * 1e3,
+                                                      "one_by_one_ms": vb["one_by_one_ms"]}
         if cpu:
             out["poly_commit_2_20"]["cpu_baseline"] = cpu_poly_baseline(gs, hg, coeffs, r[0], x[0])
     return out

@@ -78,6 +78,7 @@ SIGNATURES = {
     "bp_batch_begin": (ci, [vp, vp, sz, C.POINTER(vp)]),
     "bp_batch_axpy": (ci, [vp, sz, vp, sz, vp]),
     "bp_batch_axpy_dev": (ci, [vp, sz, vp, sz, vp]),
+    "bp_batch_axpy_s_vector": (ci, [vp, vp, sz, vp, vp, sz]),
     "bp_batch_msm": (ci, [vp, vp, vp, vp, vp, sz, vp]),
     "bp_batch_free": (None, [vp]),
     "bp_msm_aos": (ci, [vp, ci, vp, vp, sz, vp]),

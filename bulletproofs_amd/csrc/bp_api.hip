@@ -1364,6 +1364,28 @@ int bp_batch_axpy_range_agg(bp_batch* b, const uint64_t weight[4], const uint64_
   return batch_axpy(b, 0, dsc, 2 * n + 1, weight);
 }
 
+int bp_batch_axpy_s_vector(bp_batch* b, const uint64_t weight[4], size_t offset, const uint64_t* challenges,
+                           const uint64_t* challenge_invs, size_t k) {
+  if (!b || !weight || (k && (!challenges || !challenge_invs))) return BP_E_ARG;
+  bp_ctx* ctx = b->ctx;
+  if (k > 28) return fail(ctx, BP_E_ARG, "bp_batch_axpy_s_vector: too many rounds");
+  const size_t n = (size_t)1 << k;
+  if (offset > b->n || n > b->n - offset) return fail(ctx, BP_E_ARG, "bp_batch_axpy_s_vector: range outside the accumulator");
+  Guard g(ctx);
+  void *dch = nullptr, *dchi = nullptr, *dt;
+  if (k) {
+    CHK(reserve(ctx, S_IN0, k * 32, &dch));
+    CHK(reserve(ctx, S_IN1, k * 32, &dchi));
+    CHK(stage_h2d(ctx, dch, challenges, k * 32));
+    CHK(stage_h2d(ctx, dchi, challenge_invs, k * 32));
+  }
+  CHK(reserve(ctx, S_TABLE, s_vector_table_elems((int)k) * 32, &dt));
+  hipError_t e = launch_s_vector_axpy(b->bases->curve, (const u32*)dch, (const u32*)dchi, (int)k, to_arg(weight), 0, (u32*)dt,
+                                      b->acc + offset * 8, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "s_vector_axpy", e);
+  return BP_OK;
+}
+
 int bp_batch_axpy_ipa(bp_batch* b, const uint64_t weight[4], size_t g_offset, size_t h_offset, size_t u_index,
                       const uint64_t* challenges, const uint64_t* challenge_invs, size_t k, const uint64_t a[4],
                       const uint64_t bb[4], const uint64_t u_scalar[4]) {

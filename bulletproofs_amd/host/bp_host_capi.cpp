@@ -886,6 +886,110 @@ int bph_poly_roundtrip(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_
 
 }  // extern "C"
 
+// ---- several openings verified together -----------------------------------------------------------
+namespace {
+
+// `count` openings over one CRS (opening i: coefficients coeffs[i], blinder and point r_x[i], seeds + i) proved
+// one after the other, then checked together by PolyCommit::verify_batch (`reps` times, averaged) and, for
+// comparison, one by one by PolyCommit::verify.  tamper: 0 none; 1 the evaluation of opening tamper_at + 1;
+// 2 a round dropped from its proof.  batch > count cycles through the openings (the shape of the reference's
+// verify_batch benches).
+template <class Fq, class Fr, int CURVE>
+int poly_verify_batch(bp_ctx* ctx, const uint64_t* gx, const uint64_t* gy, const uint64_t* h_gen_xy, const uint64_t* coeffs,
+                      size_t n_coeffs, size_t n, const uint64_t* r_x, size_t count, size_t batch, uint64_t seed_rand,
+                      uint64_t seed_chal, int tamper, size_t tamper_at, int reps, uint64_t* out_l, uint64_t* out_r, uint64_t* out_ar,
+                      uint64_t* out_commit, uint64_t* out_eval, double* batch_ms, double* one_by_one_ms, int* ok_batch,
+                      int* ok_each) {
+  using PC = PolyCommit<Fq, Fr, CURVE>;
+  using S = ScalarOps<Fr>;
+  typename PC::Crs crs;
+  crs.gs = unpack(gx, gy, nullptr, n);
+  auto pt = [&](int k) { Affine a; memcpy(a.x, h_gen_xy + 8 * k, 32); memcpy(a.y, h_gen_xy + 8 * k + 4, 32); a.inf = 0; return a; };
+  crs.h = pt(0); crs.gen = pt(1);
+  PC::register_bases(ctx, crs);
+  struct Release { bp_bases* b; ~Release() { bp_bases_free(b); } } release{crs.bases};
+  size_t k = 0;
+  while (((size_t)1 << k) < n) k++;
+  std::vector<typename PC::Statement> sts(count);
+  std::vector<PolyProof> proofs(count);
+  for (size_t i = 0; i < count; i++) {
+    std::vector<Scalar> p = unpack_s(coeffs + 4 * n_coeffs * i, n_coeffs);
+    Scalar r, x;
+    memcpy(r.l, r_x + 8 * i, 32); memcpy(x.l, r_x + 8 * i + 4, 32);
+    sts[i] = PC::statement(ctx, crs, p, r, x);
+    SeededTranscript<Fr> t(seed_chal + i);
+    SeededRandom<Fr> rng(seed_rand + i);
+    PC::prove(ctx, crs, sts[i], p, r, t, rng, proofs[i]);
+    for (size_t j = 0; j < k; j++) {
+      memcpy(out_l + (i * k + j) * 12, proofs[i].L[j].xyz, 96);
+      memcpy(out_r + (i * k + j) * 12, proofs[i].R[j].xyz, 96);
+    }
+    memcpy(out_ar + 8 * i, proofs[i].a.l, 32); memcpy(out_ar + 8 * i + 4, proofs[i].r.l, 32);
+    memcpy(out_commit + 12 * i, sts[i].commitment.xyz, 96);
+    memcpy(out_eval + 4 * i, sts[i].evaluation.l, 32);
+  }
+  std::vector<typename PC::Statement> bst(batch);
+  std::vector<PolyProof> bpr(batch);
+  for (size_t q = 0; q < batch; q++) { bst[q] = sts[q % count]; bpr[q] = proofs[q % count]; }
+  if (tamper == 1) bst[tamper_at % batch].evaluation = S::add(bst[tamper_at % batch].evaluation, S::one());
+  if (tamper == 2 && !bpr[tamper_at % batch].L.empty()) { bpr[tamper_at % batch].L.pop_back(); bpr[tamper_at % batch].R.pop_back(); }
+  SeededTranscript<Fr> ta(seed_chal ^ 0xA1FAull);
+  const Scalar alpha = ta.verifier_scalar();
+  using clock = std::chrono::steady_clock;
+  double tb = 0, te = 0;
+  *ok_batch = 1; *ok_each = 1;
+  for (int rep = 0; rep < reps + 1; rep++) {  // the first pass grows the workspace and is not timed
+    std::vector<SeededTranscript<Fr>> ts;
+    ts.reserve(batch);
+    std::vector<typename PC::BatchItem> items(batch);
+    for (size_t q = 0; q < batch; q++) { ts.emplace_back(seed_chal + q % count); items[q] = typename PC::BatchItem{&bst[q], &bpr[q], &ts[q]}; }
+    auto t0 = clock::now();
+    const bool ok = PC::verify_batch(ctx, crs, items, alpha);
+    auto t1 = clock::now();
+    if (rep) tb += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    *ok_batch = ok ? 1 : 0;
+  }
+  {
+    auto t0 = clock::now();
+    for (size_t q = 0; q < batch; q++) {
+      SeededTranscript<Fr> t(seed_chal + q % count);
+      if (!PC::verify(ctx, crs, bst[q], bpr[q], t)) *ok_each = 0;
+    }
+    te = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
+  }
+  *batch_ms = tb / reps;
+  *one_by_one_ms = te;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int bph_poly_verify_batch(bp_ctx* ctx, int curve, const uint64_t* gx, const uint64_t* gy, const uint64_t* h_gen_xy,
+                                     const uint64_t* coeffs, size_t n_coeffs, size_t n, const uint64_t* r_x, size_t count,
+                                     size_t batch, uint64_t seed_rand, uint64_t seed_chal, int tamper, size_t tamper_at, int reps,
+                                     uint64_t* out_l, uint64_t* out_r, uint64_t* out_ar, uint64_t* out_commit, uint64_t* out_eval,
+                                     double* batch_ms, double* one_by_one_ms, int* ok_batch, int* ok_each) {
+  if (!ctx || count < 1 || batch < 1 || reps < 1 || !batch_ms || !one_by_one_ms || !ok_batch || !ok_each) return BP_E_ARG;
+  try {
+    if (curve == BP_SECP256K1)
+      return poly_verify_batch<Secp256k1Fq, Secp256k1Fr, BP_SECP256K1>(ctx, gx, gy, h_gen_xy, coeffs, n_coeffs, n, r_x, count, batch,
+                                                                      seed_rand, seed_chal, tamper, tamper_at, reps, out_l, out_r,
+                                                                      out_ar, out_commit, out_eval, batch_ms, one_by_one_ms, ok_batch,
+                                                                      ok_each);
+    if (curve == BP_VESTA)
+      return poly_verify_batch<VestaFq, VestaFr, BP_VESTA>(ctx, gx, gy, h_gen_xy, coeffs, n_coeffs, n, r_x, count, batch, seed_rand,
+                                                          seed_chal, tamper, tamper_at, reps, out_l, out_r, out_ar, out_commit,
+                                                          out_eval, batch_ms, one_by_one_ms, ok_batch, ok_each);
+    return BP_E_CURVE;
+  } catch (const VerificationError&) {
+    return BPH_E_VERIFY;
+  } catch (const std::invalid_argument&) {
+    return BP_E_ARG;
+  } catch (const std::exception&) {
+    return BP_E_HIP;
+  }
+}
+
 // ---- polynomial commitment over several ranks ------------------------------------------------
 #include "bp_host_sharded.hpp"
 

@@ -238,6 +238,40 @@ def poly_commit_roundtrip(ctx: Context, curve, gs, h_gen_xy, coeffs, r, x, seed_
     return res
 
 
+hlib.bph_poly_verify_batch.restype = ci
+hlib.bph_poly_verify_batch.argtypes = [vp, ci, vp, vp, vp, vp, sz, sz, vp, sz, sz, C.c_uint64, C.c_uint64, ci, sz, ci, vp, vp, vp, vp, vp,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci), C.POINTER(ci)]
+
+
+def poly_commit_verify_batch(ctx: Context, curve, gs, h_gen_xy, coeffs, r, x, batch=None, seed_rand=1, seed_chal=2, tamper=0,
+                             tamper_at=0, reps=1):
+    """`count` openings over one CRS (coeffs (count, n_coeffs, 4), r and x (count, 4); opening i uses the seeds + i)
+    proved, then checked together (PolyCommit::verify_batch: the MSM over the CRS once for the batch, its scalars
+    added up on the device) and one by one.  batch > count cycles through the openings.  tamper: 1 evaluation + 1,
+    2 a round dropped, at opening tamper_at of the batch."""
+    gx, gy, _ = _pts(gs)
+    n = gx.shape[0]
+    k = n.bit_length() - 1
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+    count, n_coeffs = coeffs.shape[0], coeffs.shape[1]
+    batch = count if batch is None else batch
+    rx = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.uint64).reshape(count, 4),
+                                              np.asarray(x, dtype=np.uint64).reshape(count, 4)], axis=1))
+    hg = np.ascontiguousarray(h_gen_xy, dtype=np.uint64).reshape(16)
+    L = np.zeros((count, max(k, 1), 12), dtype=np.uint64)
+    R = np.zeros((count, max(k, 1), 12), dtype=np.uint64)
+    ar = np.zeros((count, 8), dtype=np.uint64)
+    com, ev = np.zeros((count, 12), dtype=np.uint64), np.zeros((count, 4), dtype=np.uint64)
+    tb, te, okb, oke = C.c_double(), C.c_double(), ci(), ci()
+    rc = hlib.bph_poly_verify_batch(ctx.h, curve, _p(gx), _p(gy), _p(hg), _p(coeffs), n_coeffs, n, _p(rx), count, batch, seed_rand,
+                                    seed_chal, int(tamper), tamper_at, reps, _p(L), _p(R), _p(ar), _p(com), _p(ev), C.byref(tb),
+                                    C.byref(te), C.byref(okb), C.byref(oke))
+    if rc:
+        raise RuntimeError(f"bph_poly_verify_batch rc={rc}")
+    return dict(L=L[:, :k], R=R[:, :k], a=ar[:, :4], r=ar[:, 4:], commitment=com, evaluation=ev, batch_ms=tb.value,
+                one_by_one_ms=te.value, ok_batch=bool(okb.value), ok_each=bool(oke.value))
+
+
 def range_bench_inputs(ctx: Context, m, n_bits, seed):
     """Synthetic inputs of the aggregated range proof bench (benches/aggregate_range_bench.rs:30-52):
     a CRS of 2*m*n_bits + 3 random multiples of the secp256k1 generator (gs, hs, then u, g, h),

@@ -213,6 +213,13 @@ int bp_batch_axpy_range_agg(bp_batch* b, const uint64_t weight[4], const uint64_
 int bp_batch_axpy_ipa(bp_batch* b, const uint64_t weight[4], size_t g_offset, size_t h_offset,
                       size_t u_index, const uint64_t* challenges, const uint64_t* challenge_invs,
                       size_t k, const uint64_t a[4], const uint64_t bb[4], const uint64_t u_scalar[4]);
+/* One polynomial-commitment opening's share of a batch: acc[offset, +2^k) += weight * s, s the
+ * coefficients of h_poly (HPoly::coeffs, src/poly_commit/mod.rs:194-219) for the opening's k
+ * challenges -- the scalars of the CRS in poly_commit::verify's <h_poly.coeffs(), gs> (:152-159),
+ * with weight = alpha^i * a of the opening, under verify_batch_aux's scaling (src/msm.rs:91-115).
+ * Built where it is added; enqueue only. */
+int bp_batch_axpy_s_vector(bp_batch* b, const uint64_t weight[4], size_t offset, const uint64_t* challenges,
+                           const uint64_t* challenge_invs, size_t k);
 int bp_batch_msm(bp_batch* b, const uint64_t* extra_x, const uint64_t* extra_y, const uint8_t* extra_inf,
                  const uint64_t* extra_scalars, size_t n_extra, uint64_t out_xyz[12]);
 void bp_batch_free(bp_batch* b);
