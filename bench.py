@@ -172,6 +172,7 @@ def other_configs(ctx, px, py, cpu=True):
         chi = ctx.batch_inversion(C, ch)
         # CRS gs | hs | u registered once; the statement P = <a, gs> + <b, hs> + <a, b> u
         bases = ctx.register_bases(C, (px[:2 * n + 1], py[:2 * n + 1], None))
+        bases.precompute()  # window tables of the CRS (2 KiB per point, once): the session's first replacement of its generators reads them
         u_xy = np.concatenate([px[2 * n], py[2 * n]])
         wa, wb = rand_field(n), rand_field(n)
         ab = ctx.inner_product(C, wa, wb).reshape(1, 4)
