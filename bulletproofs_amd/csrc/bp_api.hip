@@ -2373,6 +2373,16 @@ struct bp_range_batch {
   u32* flag = nullptr;                          // one word
   size_t cur_n = 0;
   bool prepped = false, has_poly = false, in_ipa = false;
+  // After reb_rounds rounds the sessions' generators are replaced by the folded ones (rangeb_rebase): `row` is
+  // then the length of a row of the per-proof arrays (n before, n >> reb_rounds after), and the rounds read
+  // the batch's own points (B rows of 2 row + 1: G' | H' | u) and their window tables.
+  int reb_rounds = 0;
+  bool rebased = false;
+  size_t row = 0;
+  void* reb_block = nullptr;
+  u32 *reb_x = nullptr, *reb_y = nullptr, *reb_tab = nullptr, *reb_scratch = nullptr, *reb_cols = nullptr, *reb_prog = nullptr;
+  uint8_t* reb_inf = nullptr;
+  size_t reb_prog_words = 0;
 };
 
 namespace {
@@ -2423,6 +2433,77 @@ int rangeb_collect(bp_range_batch* rb, const MsmPlan& plan, const u32* d_win, ui
   return BP_OK;
 }
 
+// Replaces the generators of every session of the batch by the folded ones of the current length (what
+// ipa_rebase does for one session over window tables).  The H coefficients of a range proof carry y^-k,
+// which differs from column to column: ch[i + cur t] = y^-i * ch[cur t], so the folded H are built from
+// column 0's coefficients and y^-i stays behind as the new coefficient of column i.
+int rangeb_rebase(bp_range_batch* rb) {
+  bp_ctx* ctx = rb->ctx;
+  const size_t B = (size_t)rb->batch, n0 = rb->n, cur = rb->cur_n, m = n0 / cur, pts = 2 * cur + 1;
+  const bp_bases* bs = rb->bases;
+  if (!rb->reb_block) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_x = take(B * pts * 32), o_y = take(B * pts * 32), o_inf = take(B * pts);
+    const size_t o_tab = take((size_t)kTableWindows * B * pts * 64), o_scr = take((size_t)kTableWindows * B * pts * 128);
+    const size_t o_cols = take(B * 2 * m * 32), o_prog = take(B * 2 * kRebaseTabProgMax * sizeof(u32));
+    hipError_t e = hipMalloc(&rb->reb_block, off);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "rangeb_rebase: allocation", e);
+    char* base = (char*)rb->reb_block;
+    rb->reb_x = (u32*)(base + o_x); rb->reb_y = (u32*)(base + o_y); rb->reb_inf = (uint8_t*)(base + o_inf);
+    rb->reb_tab = (u32*)(base + o_tab); rb->reb_scratch = (u32*)(base + o_scr);
+    rb->reb_cols = (u32*)(base + o_cols); rb->reb_prog = (u32*)(base + o_prog);
+    rb->reb_prog_words = B * 2 * kRebaseTabProgMax;
+  }
+  // column 0 of every session's coefficients
+  hipError_t e = launch_ipab_gather_cols(rb->cg, rb->ch, (u32)n0, (u32)cur, rb->batch, rb->reb_cols, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipab_gather_cols", e);
+  const size_t col_bytes = B * 2 * m * 32;
+  CHK(reserve_pinned(ctx, col_bytes));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, rb->reb_cols, col_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const uint64_t* coef = (const uint64_t*)ctx->pinned;
+  // lanes per output: as many as fill the machine about once
+  int log_s = 0;
+  while (log_s < kRebaseTabMaxLogS && ((B * 2 * cur) << (log_s + 1)) <= 65536) log_s++;
+  if (const char* ev = getenv("BP_IPA_REBASE_LOG_S")) log_s = std::min(kRebaseTabMaxLogS, std::max(0, atoi(ev)));
+  const size_t lanes = (size_t)1 << log_s;
+  std::vector<std::vector<u32>> lists(B * 2);
+  std::vector<int> lens(B * 2, 0);
+  int longest = 1;
+  for (size_t q = 0; q < B * 2; q++) {
+    if (!rebase_tab_program(rb->curve, coef + q * m * 4, m, log_s, lists[q], &lens[q]))
+      return fail(ctx, BP_E_STATE, "rangeb_rebase: step lists too long");
+    longest = std::max(longest, lens[q]);
+  }
+  if ((size_t)longest * lanes > kRebaseTabProgMax) return fail(ctx, BP_E_STATE, "rangeb_rebase: step lists too long");
+  const size_t per_set = (size_t)longest * lanes;
+  std::vector<u32> prog(B * 2 * per_set, kRebaseTabNop);
+  for (size_t q = 0; q < B * 2; q++)
+    for (size_t lane = 0; lane < lanes; lane++)
+      memcpy(&prog[q * per_set + lane * (size_t)longest], &lists[q][lane * (size_t)lens[q]], (size_t)lens[q] * sizeof(u32));
+  HIPCHK(ctx, hipMemcpyAsync(rb->reb_prog, prog.data(), prog.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  RebaseTabSet ts[2] = {{0u, bs->inf, rb->reb_prog, rb->reb_x, rb->reb_y, rb->reb_inf},
+                        {(u32)n0, bs->inf, rb->reb_prog + per_set, rb->reb_x + cur * 8, rb->reb_y + cur * 8, rb->reb_inf + cur}};
+  for (RebaseTabSet& t : ts) { t.prog_z_stride = 2 * per_set; t.out_z_stride = pts; }
+  e = launch_ipa_rebase_tab(rb->curve, bs->tab, bs->n, ts, 2, cur, log_s, longest, ctx->stream, rb->batch);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipa_rebase_tab", e);
+  // witnesses to rows of cur elements, coefficients 1 and y^-i, u as every session's last point
+  e = launch_ipab_rebase_pack(rb->curve, rb->a, rb->b, (u32)n0, (u32)cur, rb->batch, rb->tabs, rb->tl, rb->a2, rb->b2, rb->cg, rb->ch,
+                              bs->x + 2 * n0 * 8, bs->y + 2 * n0 * 8, rb->reb_x, rb->reb_y, rb->reb_inf, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipab_rebase_pack", e);
+  std::swap(rb->a, rb->a2);
+  std::swap(rb->b, rb->b2);
+  e = launch_window_tables_inv1(rb->curve, rb->reb_x, rb->reb_y, rb->reb_inf, B * pts, kTableWindowBits, kTableWindows, rb->reb_scratch,
+                                rb->reb_tab, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, BP_E_HIP, "window_tables_inv1", e);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // `prog` goes out of scope
+  rb->row = cur;
+  rb->rebased = true;
+  rb->prepped = false;
+  return BP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2432,6 +2513,7 @@ void bp_range_batch_free(bp_range_batch* rb) {
   Guard g(rb->ctx);
   (void)hipStreamSynchronize(rb->ctx->stream);
   if (rb->block) (void)hipFree(rb->block);
+  if (rb->reb_block) (void)hipFree(rb->reb_block);
   if (rb->host) (void)hipHostFree(rb->host);
   delete rb;
 }
@@ -2448,6 +2530,15 @@ int bp_range_batch_begin(bp_ctx* ctx, const bp_bases* bases, size_t batch, size_
   bp_range_batch* rb = new (std::nothrow) bp_range_batch();
   if (!rb) return fail(ctx, BP_E_OOM, "host allocation");
   rb->ctx = ctx; rb->bases = bases; rb->curve = bases->curve; rb->batch = (int)batch; rb->m = m; rb->n = n; rb->n_bits = n_bits;
+  rb->row = n;
+  {
+    // rounds before the generators are replaced: 4 (a sixteenth of the points remains) for arguments that have
+    // at least five rounds left after them and a batch whose rounds are bound by their volume; BP_RANGE_BATCH_REBASE=0 turns it off
+    int rounds = 4;
+    if (const char* ev = getenv("BP_RANGE_BATCH_REBASE")) rounds = atoi(ev);
+    if (rounds < 1 || rounds > 8 || (n >> rounds) < 32 || batch < 4) rounds = 0;
+    rb->reb_rounds = rounds;
+  }
   // powers of y by two tables of about sqrt(n) entries
   u32 lo = 1;
   while ((size_t)lo * lo < n) lo <<= 1;
@@ -2510,6 +2601,8 @@ int bp_range_batch_commit(bp_range_batch* rb, const uint64_t* values, const uint
   Guard g(ctx);
   const size_t B = (size_t)rb->batch, n = rb->n;
   rb->has_poly = rb->in_ipa = false;
+  rb->rebased = false;
+  rb->row = n;
   CHK(stage_h2d(ctx, rb->values, values, B * rb->m * 8));
   CHK(stage_h2d(ctx, rb->sc0, alpha, B * 32));
   CHK(stage_h2d(ctx, rb->sc1, rho, B * 32));
@@ -2612,6 +2705,8 @@ int bp_range_batch_ipa_begin(bp_range_batch* rb, const uint64_t* u_factor) {
   hipError_t e = launch_ipab_init(rb->curve, rb->tabs, rb->tl, (u32)rb->n, rb->batch, rb->cg, rb->ch, ctx->stream);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipab_init", e);
   rb->cur_n = rb->n;
+  rb->row = rb->n;
+  rb->rebased = false;
   rb->prepped = false;
   rb->in_ipa = true;
   return BP_OK;
@@ -2624,7 +2719,8 @@ int bp_range_batch_round_lr(bp_range_batch* rb, uint64_t* out_lr_xyz) {
   bp_ctx* ctx = rb->ctx;
   Guard g(ctx);
   if (!rb->in_ipa || rb->cur_n < 2) return fail(ctx, BP_E_STATE, "bp_range_batch_round_lr: no round left");
-  const size_t n = rb->n, h = rb->cur_n / 2;
+  if (rb->reb_rounds && !rb->rebased && rb->row == rb->n && (rb->cur_n << rb->reb_rounds) == rb->n) CHK(rangeb_rebase(rb));
+  const size_t n = rb->row, h = rb->cur_n / 2;
   hipError_t e;
   if (!rb->prepped) {
     e = launch_ipab_round_prep(rb->curve, rb->a, rb->b, rb->cg, rb->ch, (u32)n, (u32)h, rb->batch, rb->factors, rb->eg, rb->eh,
@@ -2635,16 +2731,24 @@ int bp_range_batch_round_lr(bp_range_batch* rb, uint64_t* out_lr_xyz) {
   // L: G_hi with a_lo, H_lo with b_hi; R: G_lo with a_hi, H_hi with b_lo; u' = factor * u with factor c_l, factor c_r
   // (src/ipa/mod.rs:43-71) -- bp_ipa_round_lr's pass for every proof of the batch at once
   const bp_bases* bs = rb->bases;
-  MsmPart pg{bs->x, bs->y, bs->inf, rb->eg, n};
+  const u32 *gx = bs->x, *gy = bs->y, *hx = bs->x + n * 8, *hy = bs->y + n * 8;
+  const uint8_t *ginf = bs->inf, *hinf = bs->inf + n;
+  MsmTable table{bs->tab, bs->n};
+  if (rb->rebased) {
+    // the batch's own points: row b = G'_b (n) | H'_b (n) | u
+    gx = rb->reb_x; gy = rb->reb_y; hx = rb->reb_x + n * 8; hy = rb->reb_y + n * 8;
+    ginf = rb->reb_inf; hinf = rb->reb_inf + n;
+    table = MsmTable{rb->reb_tab, (size_t)rb->batch * (2 * n + 1), 2 * n + 1};
+  }
+  MsmPart pg{gx, gy, ginf, rb->eg, n};
   pg.sel_half = h; pg.group_hi = 0; pg.group_lo = 1;
-  MsmPart ph{bs->x + n * 8, bs->y + n * 8, bs->inf + n, rb->eh, n};
+  MsmPart ph{hx, hy, hinf, rb->eh, n};
   ph.sel_half = h; ph.group_lo = 0; ph.group_hi = 1;
   ph.tab_offset = n;
   pg.batch_stride = ph.batch_stride = n * 8;
   MsmExtra extra{{bs->x, bs->x}, {rb->dots + 16, rb->dots + 24}};
   extra.tab_index[0] = extra.tab_index[1] = 2 * n;
   extra.batch_stride[0] = extra.batch_stride[1] = 32;
-  MsmTable table{bs->tab, bs->n};
   MsmPlan plan;
   u32* d_win = nullptr;
   CHK(msm_device(ctx, rb->curve, pg, ph, &plan, &d_win, 2, &extra, &table, false, 0, rb->batch));
@@ -2661,7 +2765,7 @@ int bp_range_batch_round_fold(bp_range_batch* rb, const uint64_t* x, const uint6
   CHK(stage_h2d(ctx, rb->sc1, x_inv, B * 32));
   hipError_t e;
   if (h >= 2) {
-    e = launch_ipab_fold_prep(rb->curve, rb->a, rb->b, rb->a2, rb->b2, rb->cg, rb->ch, (u32)rb->n, (u32)h, rb->batch, rb->sc0, rb->sc1,
+    e = launch_ipab_fold_prep(rb->curve, rb->a, rb->b, rb->a2, rb->b2, rb->cg, rb->ch, (u32)rb->row, (u32)h, rb->batch, rb->sc0, rb->sc1,
                               rb->factors, rb->eg, rb->eh, rb->dots, ctx->stream);
     if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipab_fold_prep", e);
     std::swap(rb->a, rb->a2);
@@ -2669,7 +2773,7 @@ int bp_range_batch_round_fold(bp_range_batch* rb, const uint64_t* x, const uint6
     rb->prepped = true;
   } else {
     // two elements to one: the proofs' final a, b go to the pinned buffer
-    e = launch_ipab_last_fold(rb->curve, rb->a, rb->b, (u32)rb->n, rb->batch, rb->sc0, rb->sc1, (u32*)rb->host, ctx->stream);
+    e = launch_ipab_last_fold(rb->curve, rb->a, rb->b, (u32)rb->row, rb->batch, rb->sc0, rb->sc1, (u32*)rb->host, ctx->stream);
     if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipab_last_fold", e);
   }
   rb->cur_n = h;

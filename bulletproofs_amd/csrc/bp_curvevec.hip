@@ -157,6 +157,66 @@ __global__ __launch_bounds__(256) void k_window_tables(const u32* __restrict__ p
   }
 }
 
+// The same tables with ONE field inversion per base instead of one per record: the lane keeps the chain
+// 2^(c w) P in Jacobian coordinates in `scratch` (x, y, z and the product of the z before it, 128 bytes per
+// record), inverts the product of all its z once and unwinds.  `scratch`: n_windows * n * 128 bytes.
+template <class C>
+__global__ __launch_bounds__(256) void k_window_tables_inv1(const u32* __restrict__ px, const u32* __restrict__ py,
+                                                            const uint8_t* __restrict__ pinf, size_t n, int c, int n_windows,
+                                                            u32* __restrict__ scratch, u32* __restrict__ table) {
+  using F = typename C::Fq;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (pinf && pinf[i]) {
+    for (int w = 0; w < n_windows; w++) {
+      u32* rec = table + ((size_t)w * n + i) * 16;
+      fe_store(rec, fe_zero());
+      fe_store(rec + 8, fe_zero());
+    }
+    return;
+  }
+  Jac acc;
+  acc.x = fe_load(px + i * 8);
+  acc.y = fe_load(py + i * 8);
+  acc.z = fe_one<F>();
+  Fe run = fe_one<F>();
+  auto plane = [&](int w, int p) { return scratch + (((size_t)w * 4 + (size_t)p) * n + i) * 8; };
+#pragma unroll 1
+  for (int w = 0; w < n_windows; w++) {
+    if (w) {
+#pragma unroll 1
+      for (int k = 0; k < c; k++) acc = jac_dbl<F>(acc);
+    }
+    fe_store(plane(w, 0), acc.x);
+    fe_store(plane(w, 1), acc.y);
+    fe_store(plane(w, 2), acc.z);
+    fe_store(plane(w, 3), run);
+    run = fe_mul<F>(run, acc.z);  // never zero: the group order is an odd prime, no multiple of P is the identity
+  }
+  Fe inv = fe_inv<F>(run);
+#pragma unroll 1
+  for (int w = n_windows - 1; w >= 0; w--) {
+    const Fe z = fe_load(plane(w, 2));
+    const Fe zi = fe_mul<F>(inv, fe_load(plane(w, 3)));
+    inv = fe_mul<F>(inv, z);
+    const Fe zi2 = fe_sqr<F>(zi);
+    const Fe x = fe_mul<F>(fe_load(plane(w, 0)), zi2);
+    const Fe y = fe_mul<F>(fe_mul<F>(fe_load(plane(w, 1)), zi2), zi);
+    u32* rec = table + ((size_t)w * n + i) * 16;
+    fe_store(rec, fe_import<typename C::Pipeline>(x));
+    fe_store(rec + 8, fe_import<typename C::Pipeline>(y));
+  }
+}
+
+hipError_t launch_window_tables_inv1(int curve, const u32* px, const u32* py, const uint8_t* pinf, size_t n, int c,
+                                     int n_windows, u32* scratch, u32* table, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_window_tables_inv1<C>, dim3(blocks), dim3(256), 0, st, px, py, pinf, n, c,
+                                           n_windows, scratch, table));
+  return hipGetLastError();
+}
+
 hipError_t launch_window_tables(int curve, const u32* px, const u32* py, const uint8_t* pinf, size_t n, int c,
                                 int n_windows, u32* table, hipStream_t st) {
   if (n == 0) return hipSuccess;
@@ -442,7 +502,12 @@ __global__ __launch_bounds__(kRebaseTabThreads) void k_rebase_tab(RebaseTabJob j
   using F = typename P::Fq;
   __shared__ u32 pts[3 * 32 * kRebaseTabThreads];
   __shared__ u32 prog[kRebaseTabProgMax];
-  const RebaseTabSet& set = job.set[blockIdx.y];
+  // blockIdx.z: one of several problems over the same table (their own lists and outputs, z_stride apart)
+  RebaseTabSet set = job.set[blockIdx.y];
+  set.prog += (size_t)blockIdx.z * set.prog_z_stride;
+  set.ox += (size_t)blockIdx.z * set.out_z_stride * 8;
+  set.oy += (size_t)blockIdx.z * set.out_z_stride * 8;
+  set.oinf += (size_t)blockIdx.z * set.out_z_stride;
   const u32 tid = threadIdx.x, lanes = 1u << log_s;
   for (u32 k = tid; k < lanes * (u32)len; k += kRebaseTabThreads) prog[k] = set.prog[k];
   {
@@ -509,8 +574,8 @@ __global__ __launch_bounds__(kRebaseTabThreads) void k_rebase_tab(RebaseTabJob j
 }
 
 hipError_t launch_ipa_rebase_tab(int curve, const u32* table, size_t stride, const RebaseTabSet* sets, int n_sets, size_t n,
-                                 int log_s, int len, hipStream_t st) {
-  if (!table || n == 0 || n_sets < 1 || n_sets > 2 || log_s < 0 || log_s > kRebaseTabMaxLogS || len < 1 ||
+                                 int log_s, int len, hipStream_t st, int n_problems) {
+  if (!table || n == 0 || n_sets < 1 || n_sets > 2 || log_s < 0 || log_s > kRebaseTabMaxLogS || len < 1 || n_problems < 1 ||
       ((size_t)len << log_s) > kRebaseTabProgMax)
     return hipErrorInvalidValue;
   RebaseTabJob job{};
@@ -520,9 +585,11 @@ hipError_t launch_ipa_rebase_tab(int curve, const u32* table, size_t stride, con
   const unsigned bx = (unsigned)((((size_t)n << log_s) + kRebaseTabThreads - 1) / kRebaseTabThreads);
   DISPATCH_CURVE(curve, {
     if (log_s > 0)
-      hipLaunchKernelGGL((k_rebase_tab<C, true>), dim3(bx, (unsigned)n_sets), dim3(kRebaseTabThreads), 0, st, job, n, log_s, len);
+      hipLaunchKernelGGL((k_rebase_tab<C, true>), dim3(bx, (unsigned)n_sets, (unsigned)n_problems), dim3(kRebaseTabThreads), 0, st,
+                         job, n, log_s, len);
     else
-      hipLaunchKernelGGL((k_rebase_tab<C, false>), dim3(bx, (unsigned)n_sets), dim3(kRebaseTabThreads), 0, st, job, n, log_s, len);
+      hipLaunchKernelGGL((k_rebase_tab<C, false>), dim3(bx, (unsigned)n_sets, (unsigned)n_problems), dim3(kRebaseTabThreads), 0,
+                         st, job, n, log_s, len);
   });
   return hipGetLastError();
 }

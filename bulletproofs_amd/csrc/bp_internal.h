@@ -146,9 +146,15 @@ struct RebaseTabSet {
   u32* ox;
   u32* oy;
   uint8_t* oinf;
+  // several problems over the same table in one launch (n_problems > 1): problem z reads its lists
+  // prog_z_stride words and writes its outputs out_z_stride points further on
+  size_t prog_z_stride = 0, out_z_stride = 0;
 };
 hipError_t launch_ipa_rebase_tab(int curve, const u32* table, size_t stride, const RebaseTabSet* sets, int n_sets, size_t n,
-                                 int log_s, int len, hipStream_t st);
+                                 int log_s, int len, hipStream_t st, int n_problems = 1);
+// window tables (launch_window_tables) with one inversion per base; scratch: n_windows * n * 128 bytes
+hipError_t launch_window_tables_inv1(int curve, const u32* px, const u32* py, const uint8_t* pinf, size_t n, int c,
+                                     int n_windows, u32* scratch, u32* table, hipStream_t st);
 // n records of 72 bytes {x, y, infinity byte, padding} -> planes
 hipError_t launch_aos_split(const u32* aos, size_t n, u32* x, u32* y, uint8_t* inf, hipStream_t st);
 
@@ -174,6 +180,8 @@ struct MsmPart {
 struct MsmTable {
   const u32* rec = nullptr;
   size_t stride = 0;
+  // batched plans: problem b's points sit sess_stride base indices after problem 0's (0: one base set for all)
+  size_t sess_stride = 0;
 };
 constexpr int kTableWindowBits = 8;
 constexpr int kTableWindows = 32;

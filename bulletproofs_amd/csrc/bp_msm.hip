@@ -177,6 +177,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   int wbits = 0;
   while ((1 << wbits) < p.n_windows) wbits++;
   p.wshift = 31 - wbits;
+  if (batch > 1) p.wshift = 31;  // batched plans keep no window number in the value word (nothing reads it on their path)
   if (n_total >= ((size_t)1 << p.wshift)) return hipErrorInvalidValue;
   if (p.tab && (size_t)kTableWindows * table_stride >= ((size_t)1 << p.wshift)) return hipErrorInvalidValue;
   p.sort_tmp_bytes = 256;
@@ -261,6 +262,7 @@ struct DigitGroups {
   u32 extra_tab[2];  // table plans: index of the extra point in the base set
   // batched plans: problem b = blockIdx.y reads its scalars b * stride u32 further on
   u32 s_stride0 = 0, s_stride1 = 0, extra_stride[2] = {0, 0};
+  u32 tab_sess_stride = 0;  // table plans: problem b's base indices start b * tab_sess_stride further on
 };
 
 template <class C>
@@ -430,6 +432,8 @@ __global__ __launch_bounds__(1024) void k_small_front(
   s1 += (size_t)sess * sel.s_stride1;
   sel.extra_s[0] += (size_t)sess * sel.extra_stride[0];
   sel.extra_s[1] += (size_t)sess * sel.extra_stride[1];
+  if (inf0) inf0 += (size_t)sess * sel.tab_sess_stride;
+  if (inf1) inf1 += (size_t)sess * sel.tab_sess_stride;
   const u32 wid = blockIdx.x, gwid = sess * gridDim.x + wid;
   const u32 g = wid / (u32)group_windows, w = wid % (u32)group_windows;
   const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
@@ -543,10 +547,12 @@ __global__ __launch_bounds__(1024) void k_small_front(
       unsigned long long two = ((unsigned long long)hi << 32) | lo;
       raw = (u32)(two >> sh) & mask;
     }
-    u32 v = raw + carry, key, val = (u32)i | (wid << wshift);
+    const u32 wfield = wshift < 31 ? wid << wshift : 0u;  // batched plans keep no window number (msm_make_plan)
+    u32 v = raw + carry, key, val = (u32)i | wfield;
     if (tab_stride) {
-      const u32 j = is_extra ? sel.extra_tab[i - n01] : second ? tab_off1 + (u32)(i - n0) : tab_off0 + (u32)i;
-      val = (w * tab_stride + j) | (wid << wshift);
+      const u32 j = sess * sel.tab_sess_stride +
+                    (is_extra ? sel.extra_tab[i - n01] : second ? tab_off1 + (u32)(i - n0) : tab_off0 + (u32)i);
+      val = (w * tab_stride + j) | wfield;
     }
     if (v > half) {
       u32 mag = (1u << c) - v;
@@ -617,6 +623,9 @@ __global__ __launch_bounds__(1024) void k_tab_front(const u32* __restrict__ s0, 
   s1 += (size_t)sess * sel.s_stride1;
   sel.extra_s[0] += (size_t)sess * sel.extra_stride[0];
   sel.extra_s[1] += (size_t)sess * sel.extra_stride[1];
+  // problems with points of their own (tab_sess_stride != 0) have identity flags of their own, laid out as the points
+  if (inf0) inf0 += (size_t)sess * sel.tab_sess_stride;
+  if (inf1) inf1 += (size_t)sess * sel.tab_sess_stride;
   const u32 parts = (u32)group_windows / kTabFrontWindows;  // blocks per group
   const u32 g = blockIdx.x / parts, w_first = (blockIdx.x % parts) * kTabFrontWindows;
   const u32 n_groups = gridDim.x / parts;
@@ -675,7 +684,8 @@ __global__ __launch_bounds__(1024) void k_tab_front(const u32* __restrict__ s0, 
           flip = 0x80000000u;
         }
       }
-      const u32 j = is_extra ? sel.extra_tab[i - n01] : second ? tab_off1 + (u32)(i - n0) : tab_off0 + (u32)i;
+      const u32 j = sess * sel.tab_sess_stride +
+                    (is_extra ? sel.extra_tab[i - n01] : second ? tab_off1 + (u32)(i - n0) : tab_off0 + (u32)i);
       // signed digits in (-128, 128] from the bytes, low to high, with the carry of the windows below
       u32 carry = 0;
 #pragma unroll
@@ -689,8 +699,7 @@ __global__ __launch_bounds__(1024) void k_tab_front(const u32* __restrict__ s0, 
         if constexpr (!PLACE) {
           atomicAdd(&hist[slot], 1u);
         } else {
-          const u32 wid = g * (u32)group_windows + (u32)w;
-          u32 val = ((u32)w * tab_stride + j) | (wid << wshift);
+          u32 val = (u32)w * tab_stride + j;  // no window number: see msm_make_plan
           val = (carry ? val | 0x80000000u : val) ^ flip;
           sorted_vals[atomicAdd(&cursor[slot], 1u)] = val;
         }
@@ -2401,6 +2410,7 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     if (plan.batch > 1 && plan.tab_virtual && plan.group_windows % kTabFrontWindows == 0 && !no_tab_front) {
       // a batch has blocks enough for each to take several digit windows and convert a scalar once for them
       const unsigned parts = (unsigned)(plan.group_windows / kTabFrontWindows);
+      sel.tab_sess_stride = (u32)table->sess_stride;
       DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_tab_front<C>, dim3(parts * (unsigned)plan.groups, (unsigned)plan.batch),
                                                dim3(kSmallThreads), 0, st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, sel,
                                                plan.group_windows, plan.wshift, ws.vals_b, ws.bucket_start, ws.bucket_end,
@@ -2409,6 +2419,7 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
       return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1, table->rec);
     }
     // sorted entries and bucket bounds straight into the buffers the accumulation reads
+    if (plan.tab) sel.tab_sess_stride = (u32)table->sess_stride;
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_small_front<C>, dim3((unsigned)(plan.n_windows / plan.batch), (unsigned)plan.batch),
                                              dim3(kSmallThreads), 0, st,
                                              p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x, p0.y, p1.x, p1.y, ws.packed,

@@ -20,6 +20,10 @@ struct RangeBatchTabs {
 };
 // out[b][i] = draw first_draw + i of the SplitMix64 stream seeded seeds[b] as a scalar (see k_rangeb_blinders);
 // *rejected (cleared by the caller) is set when a draw was not below the modulus
+hipError_t launch_ipab_gather_cols(const u32* cg, const u32* ch, u32 n0, u32 cur, int batch, u32* out, hipStream_t st);
+hipError_t launch_ipab_rebase_pack(int curve, const u32* a, const u32* b, u32 n0, u32 cur, int batch, const u32* tabs,
+                                   RangeBatchTabs tl, u32* a2, u32* b2, u32* cg, u32* ch, const u32* ux, const u32* uy, u32* px,
+                                   u32* py, uint8_t* pinf, hipStream_t st);
 hipError_t launch_rangeb_blinders(int curve, const uint64_t* seeds, u32 first_draw, u32 count, int batch, u32* out, u32* rejected,
                                   hipStream_t st);
 // tabs[b] = the table row of proof b from yz[b] = (y, y^-1, z)

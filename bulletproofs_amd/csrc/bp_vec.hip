@@ -1116,6 +1116,60 @@ hipError_t launch_rangeb_tables(int curve, const u32* yz, RangeBatchTabs tl, u32
   return hipGetLastError();
 }
 
+// Coefficients of column 0 of B sessions whose vectors have been folded to length cur (m = n0 / cur rows of a
+// cur-column matrix per session): out[(b * 2 + 0) * m + t] = cg[b][t cur], out[(b * 2 + 1) * m + t] = ch[b][t cur].
+// The generator coefficients of a column differ from those of column 0 by a factor that depends on the column
+// alone (one for G; y^-i for the H of a range proof), so column 0 is what the folded generators are built from.
+__global__ __launch_bounds__(256) void k_ipab_gather_cols(const u32* __restrict__ cg, const u32* __restrict__ ch, u32 n0, u32 cur,
+                                                          u32 m, u32* __restrict__ out) {
+  const u32 sess = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * m * 8) return;
+  const u32 set = t / (m * 8), e = (t % (m * 8)) / 8, k = t % 8;
+  const u32* src = set ? ch : cg;
+  out[((size_t)(sess * 2 + set) * m + e) * 8 + k] = src[((size_t)sess * n0 + (size_t)e * cur) * 8 + k];
+}
+
+// After the generators of B range-proof sessions have been replaced by the folded ones (cur per vector): the
+// witnesses move to rows of cur elements (a, b -> a2, b2), the coefficients start again at cg = 1 and
+// ch_i = y^-i, and u joins every session's points as point 2 cur (points: B rows of 2 cur + 1).
+template <class F>
+__global__ __launch_bounds__(256) void k_ipab_rebase_pack(const u32* __restrict__ a, const u32* __restrict__ b, u32 n0, u32 cur,
+                                                          const u32* __restrict__ tabs, RangeBatchTabs tl, u32* __restrict__ a2,
+                                                          u32* __restrict__ b2, u32* __restrict__ cg, u32* __restrict__ ch,
+                                                          const u32* __restrict__ ux, const u32* __restrict__ uy,
+                                                          u32* __restrict__ px, u32* __restrict__ py, uint8_t* __restrict__ pinf) {
+  const u32 sess = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cur) return;
+  const size_t from = ((size_t)sess * n0 + i) * 8, to = ((size_t)sess * cur + i) * 8;
+  fe_store(a2 + to, fe_load(a + from));
+  fe_store(b2 + to, fe_load(b + from));
+  fe_store(cg + to, fe_one<F>());
+  const u32* tab = tabs + (size_t)sess * tl.row * 8;
+  fe_store(ch + to, rangeb_power<F>(tab + (size_t)tl.yilo * 8, tab + (size_t)tl.yihi * 8, tl.lo, i));
+  if (i == 0) {
+    const size_t at = (size_t)sess * (2 * cur + 1) + 2 * cur;
+    for (int k = 0; k < 8; k++) {
+      px[at * 8 + k] = ux[k];
+      py[at * 8 + k] = uy[k];
+    }
+    pinf[at] = 0;
+  }
+}
+
+hipError_t launch_ipab_gather_cols(const u32* cg, const u32* ch, u32 n0, u32 cur, int batch, u32* out, hipStream_t st) {
+  const u32 m = n0 / cur;
+  hipLaunchKernelGGL(k_ipab_gather_cols, dim3((2 * m * 8 + 255) / 256, (unsigned)batch), dim3(256), 0, st, cg, ch, n0, cur, m, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_ipab_rebase_pack(int curve, const u32* a, const u32* b, u32 n0, u32 cur, int batch, const u32* tabs,
+                                   RangeBatchTabs tl, u32* a2, u32* b2, u32* cg, u32* ch, const u32* ux, const u32* uy, u32* px,
+                                   u32* py, uint8_t* pinf, hipStream_t st) {
+  DISPATCH_FR(curve, hipLaunchKernelGGL(k_ipab_rebase_pack<F>, dim3((cur + 255) / 256, (unsigned)batch), dim3(256), 0, st, a, b, n0,
+                                        cur, tabs, tl, a2, b2, cg, ch, ux, uy, px, py, pinf));
+  return hipGetLastError();
+}
+
 // ---- integer multiply-accumulate peak probe -----------------------------------
 // 32 independent 64-bit accumulators per lane, 8 v_mad_u64_u32 each per loop
 // iteration (256 per iteration), nothing else in the loop but its counter: the

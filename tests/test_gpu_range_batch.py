@@ -92,3 +92,19 @@ def test_batch_object_rejects_bad_shapes_and_order(ctx, coracle):
         assert _lib.lib.bp_range_batch_ipa_len(rb) == 0
     finally:
         _lib.lib.bp_range_batch_free(rb)
+
+
+@pytest.mark.parametrize("rounds", ["0", "1", "2", "3"])
+def test_generator_replacement_inside_a_batch(ctx, coracle, rounds, monkeypatch):
+    """the sessions of a batch replace their generators by the folded ones after `rounds` rounds (0: never): the
+    proofs do not depend on when, or whether, that happens"""
+    from bulletproofs_amd import host_mirror
+
+    monkeypatch.setenv("BP_RANGE_BATCH_REBASE", rounds)
+    for c, m, n_bits, batch in ((o.SECP256K1, 16, 32, 6), (o.VESTA, 8, 32, 4)):
+        G, H, ugh, values, gamma = setup(coracle, c, m, n_bits, batch, SEED + 73 + int(rounds))
+        res = host_mirror.range_aggregate_prove_batch(ctx, c.id, G, H, ugh, values, gamma, n_bits, seed_rand=71, seed_chal=72, verify=True)
+        assert res["ok"]
+        for b in (0, batch - 1):
+            exp = coracle.range_agg_prove(c.id, G, H, ugh, values[b], gamma[b], n_bits, 71 + b, 72 + b, threads=coracle.max_threads())
+            assert_range_proof_equal(res["proofs"][b], exp)
