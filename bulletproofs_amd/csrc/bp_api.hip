@@ -1813,10 +1813,21 @@ int ipa_begin_common(bp_ctx* ctx, int curve, int variant, const bp_bases* res, s
 // runs.  A lane walks its run as a bucket reduction walks buckets: run += record; total += run once per
 // digit value passed; what is left below its smallest digit c, (c - 1) * run, is made by double-and-add
 // in tmp and added to total.
-bool rebase_tab_program(int curve, const uint64_t* coef, size_t m, int log_s, std::vector<u32>& out, int* len) {
-  struct Entry { u32 mag, neg, w, t; };
-  std::vector<Entry> entries;
-  entries.reserve(m * kTableWindows);
+// Length every list gets (padded with no-operations): a lane's share of the m * 32 digits, a step per
+// digit size it can pass, and the double-and-add of what is left below its smallest digit.
+size_t rebase_tab_list_len(size_t m, int log_s) {
+  const size_t lanes = (size_t)1 << log_s;
+  return (m * kTableWindows + lanes - 1) / lanes + 128 + 16;
+}
+
+// writes 2^log_s lists of rebase_tab_list_len(m, log_s) words to out; no allocation (called once per proof
+// and generator set of a batch)
+bool rebase_tab_lists(int curve, const uint64_t* coef, size_t m, int log_s, u32* out) {
+  constexpr size_t kMaxEntries = 8192;
+  if (m * kTableWindows > kMaxEntries) return false;
+  u32 unsorted[kMaxEntries], sorted[kMaxEntries];  // mag << 24 | neg << 23 | w << 16 | t
+  u32 count[130] = {0};
+  size_t n_entries = 0;
   for (size_t t = 0; t < m; t++) {
     host::HFe c;
     memcpy(c.v, coef + 4 * t, 32);
@@ -1835,47 +1846,59 @@ bool rebase_tab_program(int curve, const uint64_t* coef, size_t m, int log_s, st
       const u32 v = (u32)((c.v[w >> 3] >> (8 * (w & 7))) & 255u) + carry;
       carry = v > 128u ? 1u : 0u;
       const u32 mag = carry ? 256u - v : v;
-      if (mag) entries.push_back(Entry{mag, carry ^ flip, (u32)w, (u32)t});
+      if (mag) {
+        unsorted[n_entries++] = mag << 24 | (carry ^ flip) << 23 | (u32)w << 16 | (u32)t;
+        count[mag]++;
+      }
     }
     if (carry) return false;  // cannot happen: the value is below 2^255
   }
-  std::stable_sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.mag > b.mag; });
-  const size_t lanes = (size_t)1 << log_s, per = (entries.size() + lanes - 1) / lanes;
+  // counting sort, largest digit size first, stable
+  u32 start[130];
+  {
+    u32 at = 0;
+    for (int mag = 128; mag >= 1; mag--) { start[mag] = at; at += count[mag]; }
+  }
+  for (size_t k = 0; k < n_entries; k++) sorted[start[unsorted[k] >> 24]++] = unsorted[k];
+  const size_t lanes = (size_t)1 << log_s, per = (n_entries + lanes - 1) / lanes, len = rebase_tab_list_len(m, log_s);
   enum : u32 { RUN = 0, TOTAL = 1, TMP = 2, TABLE = 3 };
   auto step = [](u32 dst, u32 src) { return dst << 30 | src << 28; };
-  std::vector<std::vector<u32>> lists(lanes);
-  size_t longest = 1;
   for (size_t s = 0; s < lanes; s++) {
-    std::vector<u32>& l = lists[s];
-    const size_t b = std::min(entries.size(), s * per), e = std::min(entries.size(), b + per);
+    u32* l = out + s * len;
+    size_t at = 0;
+    const size_t b = std::min(n_entries, s * per), e = std::min(n_entries, b + per);
     if (b < e) {
-      u32 cur = entries[b].mag;
+      u32 cur = sorted[b] >> 24;
       for (size_t k = b; k < e; k++) {
-        for (; cur > entries[k].mag; cur--) l.push_back(step(TOTAL, RUN));
-        l.push_back(step(RUN, TABLE) | entries[k].neg << 27 | entries[k].w << 22 | entries[k].t);
+        const u32 en = sorted[k], mag = en >> 24;
+        for (; cur > mag; cur--) l[at++] = step(TOTAL, RUN);
+        l[at++] = step(RUN, TABLE) | ((en >> 23) & 1u) << 27 | ((en >> 16) & 31u) << 22 | (en & 0xFFFFu);
       }
-      l.push_back(step(TOTAL, RUN));
+      l[at++] = step(TOTAL, RUN);
       const u32 rest = cur - 1;  // the digit values below the run's smallest: total += rest * run
       if (rest) {
-        l.push_back(step(TMP, RUN));
+        l[at++] = step(TMP, RUN);
         int top = 31;
         while (!((rest >> top) & 1u)) top--;
         for (int bit = top - 1; bit >= 0; bit--) {
-          l.push_back(step(TMP, TMP));
-          if ((rest >> bit) & 1u) l.push_back(step(TMP, RUN));
+          l[at++] = step(TMP, TMP);
+          if ((rest >> bit) & 1u) l[at++] = step(TMP, RUN);
         }
-        l.push_back(step(TOTAL, TMP));
+        l[at++] = step(TOTAL, TMP);
       }
     }
-    longest = std::max(longest, l.size());
+    for (; at < len; at++) l[at] = kRebaseTabNop;
   }
-  if (longest * lanes > kRebaseTabProgMax) return false;
-  for (size_t s = 0; s < lanes; s++) {
-    lists[s].resize(longest, kRebaseTabNop);
-    out.insert(out.end(), lists[s].begin(), lists[s].end());
-  }
-  *len = (int)longest;
   return true;
+}
+
+bool rebase_tab_program(int curve, const uint64_t* coef, size_t m, int log_s, std::vector<u32>& out, int* len) {
+  const size_t l = rebase_tab_list_len(m, log_s), lanes = (size_t)1 << log_s;
+  if (l * lanes > kRebaseTabProgMax) return false;
+  const size_t at = out.size();
+  out.resize(at + l * lanes);
+  *len = (int)l;
+  return rebase_tab_lists(curve, coef, m, log_s, out.data() + at);
 }
 
 // Replaces the session's generators by the folded ones of the current length n (see
@@ -2468,20 +2491,13 @@ int rangeb_rebase(bp_range_batch* rb) {
   while (log_s < kRebaseTabMaxLogS && ((B * 2 * cur) << (log_s + 1)) <= 65536) log_s++;
   if (const char* ev = getenv("BP_IPA_REBASE_LOG_S")) log_s = std::min(kRebaseTabMaxLogS, std::max(0, atoi(ev)));
   const size_t lanes = (size_t)1 << log_s;
-  std::vector<std::vector<u32>> lists(B * 2);
-  std::vector<int> lens(B * 2, 0);
-  int longest = 1;
-  for (size_t q = 0; q < B * 2; q++) {
-    if (!rebase_tab_program(rb->curve, coef + q * m * 4, m, log_s, lists[q], &lens[q]))
-      return fail(ctx, BP_E_STATE, "rangeb_rebase: step lists too long");
-    longest = std::max(longest, lens[q]);
-  }
+  const int longest = (int)rebase_tab_list_len(m, log_s);
   if ((size_t)longest * lanes > kRebaseTabProgMax) return fail(ctx, BP_E_STATE, "rangeb_rebase: step lists too long");
   const size_t per_set = (size_t)longest * lanes;
-  std::vector<u32> prog(B * 2 * per_set, kRebaseTabNop);
+  std::vector<u32> prog(B * 2 * per_set);
   for (size_t q = 0; q < B * 2; q++)
-    for (size_t lane = 0; lane < lanes; lane++)
-      memcpy(&prog[q * per_set + lane * (size_t)longest], &lists[q][lane * (size_t)lens[q]], (size_t)lens[q] * sizeof(u32));
+    if (!rebase_tab_lists(rb->curve, coef + q * m * 4, m, log_s, &prog[q * per_set]))
+      return fail(ctx, BP_E_STATE, "rangeb_rebase: step lists");
   HIPCHK(ctx, hipMemcpyAsync(rb->reb_prog, prog.data(), prog.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
   RebaseTabSet ts[2] = {{0u, bs->inf, rb->reb_prog, rb->reb_x, rb->reb_y, rb->reb_inf},
                         {(u32)n0, bs->inf, rb->reb_prog + per_set, rb->reb_x + cur * 8, rb->reb_y + cur * 8, rb->reb_inf + cur}};

@@ -194,14 +194,23 @@ __global__ __launch_bounds__(256) void k_window_tables_inv1(const u32* __restric
     run = fe_mul<F>(run, acc.z);  // never zero: the group order is an odd prime, no multiple of P is the identity
   }
   Fe inv = fe_inv<F>(run);
+  // the record below is loaded while this one is normalised: the loads do not depend on the running inverse
+  Fe nx = fe_load(plane(n_windows - 1, 0)), ny = fe_load(plane(n_windows - 1, 1)), nz = fe_load(plane(n_windows - 1, 2)),
+     np = fe_load(plane(n_windows - 1, 3));
 #pragma unroll 1
   for (int w = n_windows - 1; w >= 0; w--) {
-    const Fe z = fe_load(plane(w, 2));
-    const Fe zi = fe_mul<F>(inv, fe_load(plane(w, 3)));
+    const Fe cx = nx, cy = ny, z = nz, pre = np;
+    if (w > 0) {
+      nx = fe_load(plane(w - 1, 0));
+      ny = fe_load(plane(w - 1, 1));
+      nz = fe_load(plane(w - 1, 2));
+      np = fe_load(plane(w - 1, 3));
+    }
+    const Fe zi = fe_mul<F>(inv, pre);
     inv = fe_mul<F>(inv, z);
     const Fe zi2 = fe_sqr<F>(zi);
-    const Fe x = fe_mul<F>(fe_load(plane(w, 0)), zi2);
-    const Fe y = fe_mul<F>(fe_mul<F>(fe_load(plane(w, 1)), zi2), zi);
+    const Fe x = fe_mul<F>(cx, zi2);
+    const Fe y = fe_mul<F>(fe_mul<F>(cy, zi2), zi);
     u32* rec = table + ((size_t)w * n + i) * 16;
     fe_store(rec, fe_import<typename C::Pipeline>(x));
     fe_store(rec + 8, fe_import<typename C::Pipeline>(y));
