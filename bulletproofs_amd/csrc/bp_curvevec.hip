@@ -476,7 +476,7 @@ struct RebaseTabJob {
   RebaseTabSet set[2];
 };
 
-constexpr u32 kRebaseTabThreads = 128;
+constexpr u32 kRebaseTabThreads = 256;
 
 // point `which` of lane `lane` of a block: word k at (which * 32 + k) * kRebaseTabThreads + lane
 BP_DEV Xyzz rebase_lds_load(const u32* pts, u32 which, u32 lane) {
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kRebaseTabThreads) void k_rebase_tab(RebaseTabJob j
   using P = typename C::Pipeline;
   using F = typename P::Fq;
   __shared__ u32 pts[3 * 32 * kRebaseTabThreads];
-  __shared__ u32 prog[kRebaseTabProgMax];
+  extern __shared__ u32 prog[];  // the lists: (len << log_s) words
   // blockIdx.z: one of several problems over the same table (their own lists and outputs, z_stride apart)
   RebaseTabSet set = job.set[blockIdx.y];
   set.prog += (size_t)blockIdx.z * set.prog_z_stride;
@@ -592,13 +592,14 @@ hipError_t launch_ipa_rebase_tab(int curve, const u32* table, size_t stride, con
   job.stride = stride;
   for (int k = 0; k < n_sets; k++) job.set[k] = sets[k];
   const unsigned bx = (unsigned)((((size_t)n << log_s) + kRebaseTabThreads - 1) / kRebaseTabThreads);
+  const size_t prog_bytes = ((size_t)len << log_s) * sizeof(u32);
   DISPATCH_CURVE(curve, {
     if (log_s > 0)
-      hipLaunchKernelGGL((k_rebase_tab<C, true>), dim3(bx, (unsigned)n_sets, (unsigned)n_problems), dim3(kRebaseTabThreads), 0, st,
-                         job, n, log_s, len);
+      hipLaunchKernelGGL((k_rebase_tab<C, true>), dim3(bx, (unsigned)n_sets, (unsigned)n_problems), dim3(kRebaseTabThreads),
+                         prog_bytes, st, job, n, log_s, len);
     else
-      hipLaunchKernelGGL((k_rebase_tab<C, false>), dim3(bx, (unsigned)n_sets, (unsigned)n_problems), dim3(kRebaseTabThreads), 0,
-                         st, job, n, log_s, len);
+      hipLaunchKernelGGL((k_rebase_tab<C, false>), dim3(bx, (unsigned)n_sets, (unsigned)n_problems), dim3(kRebaseTabThreads),
+                         prog_bytes, st, job, n, log_s, len);
   });
   return hipGetLastError();
 }
