@@ -204,6 +204,7 @@ struct MsmPlan {
   u32 n_segs;     // per window
   bool small;     // one-launch front end (digits, counting sort, bounds) per window, tree accumulation
   bool mid;       // sliced counting sort (three launches), tree accumulation
+  int mid_iters;  // sliced counting sort: points per lane and slice (a slice is 1024 * mid_iters points)
   bool tab;       // points come from window tables: all digit windows share one bucket set per group
   // table plan small enough for the one-launch front end: the digit windows keep their own bucket
   // sets (the launches are those of the plan without tables, only the points read differ) and the

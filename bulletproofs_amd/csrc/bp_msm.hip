@@ -59,6 +59,7 @@ constexpr u32 kSmallMaxBuckets = 4096;
 // the sliced counting sort for mid-sized problems (k_mid_*)
 constexpr int kMidIters = 8;
 constexpr u32 kMidSlice = kSmallThreads * kMidIters;
+constexpr int kMidWindowsPerBlock = 4;  // k_mid_count_multi
 constexpr u32 kMidMaxBuckets = 256;
 constexpr int kTwoLevelLoBits = 8;       // see the two-level counting sort
 constexpr u32 kTwoLevelMaxBins = 4096;
@@ -213,10 +214,14 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
     size_t need = (size_t)p.n_windows * (p.tab && !p.tab_virtual ? p.entries : n_total) * sizeof(u32);
     if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
   }
+  // Short slices where the windows of a slice share a block (k_mid_count_multi): the blocks of a launch stay
+  // as many as the CUs while a scalar is converted once per four windows
+  p.mid_iters = (p.mid && !p.tab && n_total <= ((size_t)1 << 18) && p.digit_windows % kMidWindowsPerBlock == 0 &&
+                 !getenv("BP_MSM_MID_SINGLE")) ? 2 : kMidIters;
   if (p.mid) {
     // the sliced counting sort keeps one histogram per (group, digit window, slice) in the second
     // key buffer: a size that does not shrink with n (16 KiB per group at one slice)
-    const size_t n_slices = (n_total + kMidSlice - 1) / kMidSlice;
+    const size_t n_slices = (n_total + (size_t)kSmallThreads * p.mid_iters - 1) / ((size_t)kSmallThreads * p.mid_iters);
     size_t need = (size_t)groups * p.digit_windows * n_slices * p.n_buckets * sizeof(u32);
     if (need > p.keys_bytes) p.keys_bytes = (need + 255) & ~(size_t)255;
   }
@@ -867,6 +872,115 @@ __global__ __launch_bounds__(1024) void k_mid_count(
   }
 }
 
+// k_mid_count for plans without tables with kMidWindowsPerBlock windows of a slice per block: a scalar is
+// converted to an integer (a Montgomery product) and folded to |k| <= r/2 once for them, where the
+// one-window blocks repeat that for every window.  Slices are `iters` points per lane.
+template <class C>
+__global__ __launch_bounds__(1024) void k_mid_count_multi(
+    const u32* __restrict__ s0, const uint8_t* __restrict__ inf0, size_t n0, const u32* __restrict__ s1,
+    const uint8_t* __restrict__ inf1, size_t n1, const u32* __restrict__ x0, const u32* __restrict__ y0,
+    const u32* __restrict__ x1, const u32* __restrict__ y1, u32* __restrict__ packed, DigitGroups sel, int c,
+    int group_windows, int groups, u32 n_buckets, u32 n_slices, int iters, u32* __restrict__ tmp,
+    u32* __restrict__ ghist, u32* __restrict__ heavy_count) {
+  using Fr = typename C::Fr;
+  __shared__ u32 hist[kMidWindowsPerBlock * 2 * kMidMaxBuckets];
+  __shared__ u32 thr[kMidWindowsPerBlock][8], msk[kMidWindowsPerBlock][8];
+  const u32 slice = blockIdx.x, w_first = blockIdx.y * kMidWindowsPerBlock;
+  const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
+  const u32 half = 1u << (c - 1), mask = (1u << c) - 1;
+  for (u32 b = threadIdx.x; b < kMidWindowsPerBlock * 2 * n_buckets; b += kSmallThreads) hist[b] = 0;
+  if (threadIdx.x < kMidWindowsPerBlock) window_carry_consts(w_first + threadIdx.x, c, thr[threadIdx.x], msk[threadIdx.x]);
+  if (threadIdx.x == 0 && slice == 0 && blockIdx.y == 0) *heavy_count = 0;
+  __syncthreads();
+  const u32 invalid = n_buckets;
+  const size_t slice_points = (size_t)kSmallThreads * (size_t)iters;
+#pragma unroll 1
+  for (int it = 0; it < iters; it++) {
+    const size_t i = (size_t)slice * slice_points + (size_t)it * kSmallThreads + threadIdx.x;
+    if (i >= n) continue;
+    const bool is_extra = i >= n01, second = i >= n0;
+    const u32 grp = digit_group_of(sel, i, n0, n01);
+    if ((u32)(i % (size_t)gridDim.y) == blockIdx.y) {  // packed once, spread over the window blocks
+      const u32* px = second ? x1 + (i - n0) * 8 : x0 + i * 8;
+      const u32* py = second ? y1 + (i - n0) * 8 : y0 + i * 8;
+      if (is_extra) {
+        px = sel.extra_xy[i - n01];
+        py = px + 8;
+      }
+      fe_store(packed + i * 16, fe_import<C>(fe_load(px)));
+      fe_store(packed + i * 16 + 8, fe_import<C>(fe_load(py)));
+    }
+    const u32* sp = second ? s1 + (i - n0) * 8 : s0 + i * 8;
+    if (is_extra) sp = sel.extra_s[i - n01];
+    const bool is_inf = is_extra ? false : (second ? (inf1 && inf1[i - n0]) : (inf0 && inf0[i]));
+    Fe k = fe_from_mont<Fr>(fe_load(sp));
+    u32 flip = 0;
+    {
+      Fe nk = fe_neg<Fr>(k);
+      bool gt = false, decided = false;
+#pragma unroll
+      for (int t = 7; t >= 0; t--) {
+        if (!decided && k.v[t] != nk.v[t]) {
+          gt = k.v[t] > nk.v[t];
+          decided = true;
+        }
+      }
+      if (gt) {
+        k = nk;
+        flip = 0x80000000u;
+      }
+    }
+#pragma unroll 1
+    for (u32 wl = 0; wl < (u32)kMidWindowsPerBlock; wl++) {
+      const u32 w = w_first + wl;
+      u32 carry = 0;
+      {
+        bool gt = false, decided = false;
+#pragma unroll
+        for (int t = 7; t >= 0; t--) {
+          u32 kv = k.v[t] & msk[wl][t], tv = thr[wl][t];
+          if (!decided && kv != tv) {
+            gt = kv > tv;
+            decided = true;
+          }
+        }
+        carry = gt ? 1u : 0u;
+      }
+      const int bit0 = (int)(w * (u32)c), limb = bit0 >> 5, sh = bit0 & 31;
+      u32 raw = 0;
+      if (limb < 8) {
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+          lo = (t == limb) ? k.v[t] : lo;
+          hi = (t == limb + 1) ? k.v[t] : hi;
+        }
+        unsigned long long two = ((unsigned long long)hi << 32) | lo;
+        raw = (u32)(two >> sh) & mask;
+      }
+      u32 v = raw + carry, key, sign = flip;
+      if (v > half) {
+        u32 mag = (1u << c) - v;
+        key = mag ? mag - 1 : invalid;
+        sign ^= 0x80000000u;
+      } else {
+        key = v ? v - 1 : invalid;
+      }
+      if (is_inf) key = invalid;
+      u32 rank = 0;
+      if (key != invalid) rank = atomicAdd(&hist[(wl * 2 + grp) * n_buckets + key], 1u);
+      tmp[(size_t)w * n + i] = key | (rank << 12) | sign;
+    }
+  }
+  __syncthreads();
+  for (u32 q = threadIdx.x; q < (u32)kMidWindowsPerBlock * (u32)groups * n_buckets; q += kSmallThreads) {
+    const u32 wl = q / ((u32)groups * n_buckets), r = q % ((u32)groups * n_buckets);
+    const u32 g = r / n_buckets, b = r % n_buckets;
+    const u32 wid = g * (u32)group_windows + w_first + wl;
+    ghist[((size_t)wid * n_slices + slice) * n_buckets + b] = hist[(wl * 2 + g) * n_buckets + b];
+  }
+}
+
 // one block of n_buckets lanes per (group, window): ghist[wid][s][b] becomes the number of
 // entries of bucket b in the slices before s; the bucket bounds follow from the totals
 __global__ __launch_bounds__(256) void k_mid_offsets(u32* __restrict__ ghist, u32 n_buckets, u32 n_slices, size_t stride,
@@ -894,13 +1008,13 @@ __global__ __launch_bounds__(1024) void k_mid_scatter(const u32* __restrict__ tm
                                                       size_t n0, size_t n1, int group_windows, u32 n_buckets,
                                                       u32 n_slices, int wshift, int tab, size_t tab_stride,
                                                       size_t tab_off0, size_t tab_off1,
-                                                      u32* __restrict__ sorted_vals) {
+                                                      u32* __restrict__ sorted_vals, int iters) {
   const u32 slice = blockIdx.x, w = blockIdx.y;
   const u32 sl = tab ? w * n_slices + slice : slice;
   const u32 ns = tab ? (u32)gridDim.y * n_slices : n_slices;
   const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
-  for (int it = 0; it < kMidIters; it++) {
-    size_t i = (size_t)slice * kMidSlice + (size_t)it * kSmallThreads + threadIdx.x;
+  for (int it = 0; it < iters; it++) {
+    size_t i = (size_t)slice * ((size_t)kSmallThreads * (size_t)iters) + (size_t)it * kSmallThreads + threadIdx.x;
     if (i >= n) continue;
     const u32 t = tmp[(size_t)w * n + i];
     const u32 key = t & 0xfffu;
@@ -2430,22 +2544,30 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1, plan.tab ? table->rec : nullptr);
   }
   if (plan.mid) {
-    const u32 n_slices = (u32)((n + kMidSlice - 1) / kMidSlice);
+    const size_t slice_points = (size_t)kSmallThreads * (size_t)plan.mid_iters;
+    const u32 n_slices = (u32)((n + slice_points - 1) / slice_points);
     const int tab = plan.tab ? 1 : 0;
     const u32 n_slices_eff = tab ? n_slices * (u32)plan.digit_windows : n_slices;
     const size_t stride = tab ? plan.entries : n;  // sorted entries per output window
     u32* tmp_words = ws.keys_a;  // digit_windows * n words
     u32* ghist = ws.keys_b;      // n_windows * n_slices_eff * n_buckets words
-    DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_mid_count<C>, dim3(n_slices, (unsigned)plan.digit_windows),
-                                             dim3(kSmallThreads), 0, st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x,
-                                             p0.y, p1.x, p1.y, ws.packed, sel, plan.c, plan.group_windows, plan.groups,
-                                             plan.n_buckets, n_slices, tab, tmp_words, ghist, ws.heavy_count));
+    if (plan.mid_iters != kMidIters) {
+      DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_mid_count_multi<C>, dim3(n_slices, (unsigned)(plan.digit_windows / kMidWindowsPerBlock)),
+                                               dim3(kSmallThreads), 0, st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x, p0.y,
+                                               p1.x, p1.y, ws.packed, sel, plan.c, plan.group_windows, plan.groups, plan.n_buckets,
+                                               n_slices, plan.mid_iters, tmp_words, ghist, ws.heavy_count));
+    } else {
+      DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_mid_count<C>, dim3(n_slices, (unsigned)plan.digit_windows),
+                                               dim3(kSmallThreads), 0, st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x,
+                                               p0.y, p1.x, p1.y, ws.packed, sel, plan.c, plan.group_windows, plan.groups,
+                                               plan.n_buckets, n_slices, tab, tmp_words, ghist, ws.heavy_count));
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(k_mid_offsets, dim3((unsigned)plan.n_windows), dim3(plan.n_buckets), 0, st, ghist, plan.n_buckets,
                        n_slices_eff, stride, ws.bucket_start, ws.bucket_end);
     hipLaunchKernelGGL(k_mid_scatter, dim3(n_slices, (unsigned)plan.digit_windows), dim3(kSmallThreads), 0, st, tmp_words,
                        ghist, ws.bucket_start, sel, p0.n, p1.n, plan.group_windows, plan.n_buckets, n_slices, plan.wshift,
-                       tab, tab ? table->stride : 0, p0.tab_offset, p1.tab_offset, ws.vals_b);
+                       tab, tab ? table->stride : 0, p0.tab_offset, p1.tab_offset, ws.vals_b, plan.mid_iters);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1, tab ? table->rec : nullptr);
   }
