@@ -2550,7 +2550,7 @@ int bp_range_batch_begin(bp_ctx* ctx, const bp_bases* bases, size_t batch, size_
   if (bases->ctx != ctx) return fail(ctx, BP_E_ARG, "bp_range_batch_begin: bases belong to another context");
   const size_t n = m * (size_t)n_bits;
   if (batch < 1 || batch > (size_t)kMsmMaxBatch || m == 0 || n_bits == 0 || n_bits > 64 || n < 2 || (n & (n - 1)) || n > 4096)
-    return fail(ctx, BP_E_ARG, "bp_range_batch_begin: 1 <= batch <= 64, m * n_bits a power of two in 2..4096");
+    return fail(ctx, BP_E_ARG, "bp_range_batch_begin: 1 <= batch <= 128, m * n_bits a power of two in 2..4096");
   if (bases->n < 2 * n + 3) return fail(ctx, BP_E_ARG, "bp_range_batch_begin: base set shorter than gs | hs | u | g | h (2 m n_bits + 3)");
   if (!bases->tab) return fail(ctx, BP_E_STATE, "bp_range_batch_begin: the base set has no window tables (bp_bases_precompute)");
   Guard g(ctx);

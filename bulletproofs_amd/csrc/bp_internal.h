@@ -239,7 +239,7 @@ int msm_choose_window(size_t n);
 int msm_default_window(size_t n);
 hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride = 0,
                          bool allow_stages = false, int batch = 1);
-constexpr int kMsmMaxBatch = 64;
+constexpr int kMsmMaxBatch = 128;
 // out[q] = sum of the `count` XYZZ points (AoS, 32 words, boundary form) in + (q * count) * 32, q < n_sums: the
 // window sums of a table plan whose windows carry their powers of two already (finish_c == 0), added on the
 // device; out may be host memory the device can write

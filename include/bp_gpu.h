@@ -268,7 +268,7 @@ int bp_range_agg_eval(bp_ctx* ctx, int curve, const uint64_t x[4], size_t n, uin
                       uint64_t t_hat[4]);
 /* ---- batches of aggregated range proofs -----------------------------------
  * B proofs of one shape (m values of n_bits bits, N = m * n_bits a power of two, 2 <= N <= 4096,
- * B <= 64) proved together: each phase of range::aggregate::prove (src/range/aggregate.rs:23-170) and
+ * B <= 128) proved together: each phase of range::aggregate::prove (src/range/aggregate.rs:23-170) and
  * each round of the inner-product argument (src/ipa/mod.rs:38-97) is ONE chain of launches whose
  * grids serve all B proofs, so a host thread pays the launch and synchronisation latency of a
  * proof once per batch.  Proof b's messages are those of the single-proof calls on its inputs.

@@ -24,10 +24,10 @@ def setup(coracle, c, m, n_bits, batch, seed):
 
 
 @pytest.mark.parametrize("c", [o.SECP256K1, o.VESTA], ids=lambda c: c.name)
-@pytest.mark.parametrize("m,n_bits,batch", [(64, 64, 16), (8, 32, 5), (1, 64, 64), (2, 1, 3), (1, 8, 1)])
+@pytest.mark.parametrize("m,n_bits,batch", [(64, 64, 16), (8, 32, 5), (1, 64, 64), (4, 16, 128), (2, 1, 3), (1, 8, 1)])
 def test_every_proof_of_a_batch_equals_the_oracles(ctx, coracle, c, m, n_bits, batch):
     """(64, 64, 16) is the shape of benches/aggregate_range_bench.rs; the others: a batch that is not a
-    power of two, the single-value proof at the largest batch, N = 2 (one round), a batch of one"""
+    power of two, the single-value proof at a large batch, the largest batch, N = 2 (one round), a batch of one"""
     from bulletproofs_amd import host_mirror
 
     if c is o.VESTA and m == 64:
@@ -76,7 +76,7 @@ def test_batch_object_rejects_bad_shapes_and_order(ctx, coracle):
     # no window tables yet
     assert _lib.lib.bp_range_batch_begin(ctx.h, bases.h, 4, 2, 8, C.byref(rb)) == _lib.BP_E_STATE
     bases.precompute()
-    assert _lib.lib.bp_range_batch_begin(ctx.h, bases.h, 65, 2, 8, C.byref(rb)) == _lib.BP_E_ARG      # batch too large
+    assert _lib.lib.bp_range_batch_begin(ctx.h, bases.h, 129, 2, 8, C.byref(rb)) == _lib.BP_E_ARG     # batch too large
     assert _lib.lib.bp_range_batch_begin(ctx.h, bases.h, 4, 3, 8, C.byref(rb)) == _lib.BP_E_ARG       # N not a power of two
     assert _lib.lib.bp_range_batch_begin(ctx.h, bases.h, 4, 4, 8, C.byref(rb)) == _lib.BP_E_ARG       # base set too short
     assert _lib.lib.bp_range_batch_begin(ctx.h, bases.h, 4, 2, 8, C.byref(rb)) == _lib.BP_OK
