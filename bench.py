@@ -583,6 +583,7 @@ def main():
     ap.add_argument("--no-range", action="store_true", help="skip the aggregated range proof figures")
     ap.add_argument("--no-in-flight", action="store_true", help="skip the two-MSMs-in-flight figure")
     ap.add_argument("--no-streaming", action="store_true", help="skip the fold / dot / s-vector bandwidth figures")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the 2^16 .. 2^20 MSM figures (profiles of the headline kernel alone)")
     ap.add_argument("--no-dist-legs", action="store_true", help="N > 1: only the headline MSM, none of the other multi-GPU legs")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 2^log2n points on every GPU; strong: 2^log2n points in total, split by shard_range")
@@ -728,7 +729,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n)
         if not args.no_range and world == 1:
             out["range_proofs"] = range_proofs(ctx, local_rank, cpu=not args.no_cpu_baseline)
-        if world == 1:
+        if world == 1 and not args.no_sizes:
             out["msm_sizes"] = msm_sizes(ctx, bp, dx, dy, dk, n, args.steps)
         if world == 1 and not args.no_in_flight:
             out["msm_two_in_flight"] = msm_in_flight(bp, local_rank, dx, dy, dk, n, args.steps)
