@@ -391,6 +391,29 @@ def range_proofs(ctx, device, workers=8, per_worker=8, cpu=True, extras=True):
         raise SystemExit("a proof of the batch of 128 failed to verify")
     pb2 = host_mirror.range_aggregate_prove_batch(ctx, bp.SECP256K1, gs, hs, ugh, pvals2, pgam2, 64, seed, seed + 1, reps=3)
     batched["batch_128"] = {"batch_ms": pb2["batch_ms"], "prove_per_s": pb2["per_s"]}
+    # two host threads, a context and a batch of 128 each: one batch's short launches run beside the other's long ones
+    import threading
+
+    flight = [None, None]
+    ctxs = [bp.Context(device) for _ in flight]
+
+    def in_flight(k):
+        host_mirror.range_aggregate_prove_batch(ctxs[k], bp.SECP256K1, gs, hs, ugh, pvals2, pgam2, 64, seed, seed + 1, reps=1)
+        flight[k] = host_mirror.range_aggregate_prove_batch(ctxs[k], bp.SECP256K1, gs, hs, ugh, pvals2, pgam2, 64, seed, seed + 1, reps=4)
+
+    workers_ = [threading.Thread(target=in_flight, args=(k,)) for k in range(len(flight))]
+    for w_ in workers_:
+        w_.start()
+    for w_ in workers_:
+        w_.join()
+    if any(f is None for f in flight):
+        raise SystemExit("a batch in flight failed")
+    batched["two_batches_of_128_in_flight"] = {"host_threads": 2, "batch_ms_each": [f["batch_ms"] for f in flight],
+                                               "prove_per_s": sum(128.0 / f["batch_ms"] * 1e3 for f in flight),
+                                               "note": "each thread's own clock over its timed batches; the threads start together "
+                                                       "and run the same number of batches"}
+    for c_ in ctxs:
+        c_.close()
     if not extras:  # the figures that are summed over the GPUs of a node
         return {"workload": "m = 64 values x 64 bits (N = 4096), secp256k1, prove and verify, 1 GPU", "prove_per_s": thr["prove_per_s"],
                 "verify_per_s": thr["verify_per_s"], "host_threads": workers, "prove_batch_64": batched,
