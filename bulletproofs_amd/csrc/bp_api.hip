@@ -2875,8 +2875,33 @@ int bp_microbench(bp_ctx* ctx, int id, int blocks, int iters, float* ms) {
     v = (uint32_t)(s >> 33);
   }
   for (size_t i = 7; i < seed.size(); i += 8) seed[i] &= 0x3fffffffu;  // below every modulus
-  if (id == 8) seed[0] = 0;  // the self-check counts disagreeing lanes there
+  if (id == 8 || id == 12) seed[0] = 0;  // the self-checks count disagreeing lanes there
   HIPCHK(ctx, hipMemcpyAsync(io, seed.data(), seed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (id == 12) {
+    hipError_t ce = launch_batch_affine_check(blocks, (u32*)io, ctx->stream);
+    if (ce != hipSuccess) return fail(ctx, BP_E_HIP, "bp_microbench", ce);
+    uint32_t bad = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&bad, io, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *ms = (float)bad;
+    return BP_OK;
+  }
+  if (id == 11) {
+    const size_t park_bytes = (size_t)blocks * 128 * (size_t)iters * 32;
+    if (park_bytes > ((size_t)8 << 30)) return fail(ctx, BP_E_ARG, "bp_microbench: id 11 takes blocks * 128 * iters * 32 <= 8 GiB");
+    void *park, *sink;
+    CHK(reserve(ctx, S_PACKED, park_bytes, &park));
+    CHK(reserve(ctx, S_SMALL, 256, &sink));
+    hipError_t be = launch_batch_affine_bench(blocks, iters, (const u32*)io, (u32*)park, (u32*)sink, ctx->stream);
+    if (be != hipSuccess) return fail(ctx, BP_E_HIP, "bp_microbench", be);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    be = launch_batch_affine_bench(blocks, iters, (const u32*)io, (u32*)park, (u32*)sink, ctx->stream);
+    if (be != hipSuccess) return fail(ctx, BP_E_HIP, "bp_microbench", be);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev[4], ctx->ev[5]));
+    return BP_OK;
+  }
   if (id == 8) {
     hipError_t ce = launch_microbench(id, blocks, iters, (u32*)io, ctx->stream);
     if (ce != hipSuccess) return fail(ctx, BP_E_HIP, "bp_microbench", ce);

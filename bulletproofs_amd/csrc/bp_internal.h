@@ -83,6 +83,9 @@ hipError_t launch_int_mad_peak(int iters, u32* sink, int blocks, hipStream_t st)
 hipError_t launch_microbench(int id, int blocks, int iters, u32* io, hipStream_t st);
 // records: power of two; table: records * 16 u32
 hipError_t launch_gather_bench(const u32* table, size_t records, u32* sink, hipStream_t st);
+// batch-affine additions (bp_microbench ids 11, 12): park = blocks * 128 * iters field elements
+hipError_t launch_batch_affine_bench(int blocks, int iters, const u32* io, u32* park, u32* sink, hipStream_t st);
+hipError_t launch_batch_affine_check(int blocks, u32* io, hipStream_t st);
 
 // ---- curve-vector kernels (bp_curvevec.hip) ----
 // scalars are canonical (non-Montgomery) little-endian 256-bit integers here

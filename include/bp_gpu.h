@@ -493,7 +493,12 @@ int bp_bench_int_mad_peak(bp_ctx* ctx, int iters, double* mac_per_s);
  * the representation the MSM pipeline uses internally; id 8 = self-check of that multiply against
  * its portable form over chains of `iters` products: *ms receives the number of lanes that
  * disagreed (0 = pass); id 9 = as 0 on the scalar field of secp256k1 (the multiply of the
- * streaming kernels), id 10 = 2*iters dual products a*b + c*d with one reduction on that field. */
+ * streaming kernels), id 10 = 2*iters dual products a*b + c*d with one reduction on that field;
+ * id 11 = `iters` independent affine additions per lane with one field inversion for all of them
+ * (batch-affine accumulation: 6 products per addition, the running products parked in memory;
+ * 128 lanes per block, operands made in registers), id 12 = self-check of that arithmetic on
+ * multiples of the secp256k1 generator against the XYZZ formulas (*ms = lanes that disagreed,
+ * 64 lanes per block, `iters` ignored). */
 int bp_microbench(bp_ctx* ctx, int id, int blocks, int iters, float* ms);
 /* The event markers behind bp_last_kernel_ms for MSMs (four per MSM, a few microseconds each on the
  * stream) can be turned off for latency-bound callers (the IPA rounds of a proof); on by default.
