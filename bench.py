@@ -505,12 +505,15 @@ def distributed_legs(ctx, bp, torch, dist, rank, world, local_rank, sharded_cls,
     # (3) aggregated range proofs: every GPU proves and verifies its own proofs
     if not args.no_range:
         mine = range_proofs(ctx, local_rank, cpu=False, extras=False)
-        t = torch.tensor([mine["prove_per_s"], mine["verify_per_s"]], dtype=torch.float64, device="cuda")
+        t = torch.tensor([mine["prove_per_s"], mine["verify_per_s"], mine["prove_batch_64"]["batch_128"]["prove_per_s"]],
+                         dtype=torch.float64, device="cuda")
         per_gpu = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(per_gpu, t)
         out["range_proofs"] = {"metric": "aggregated 64-bit range proofs/sec", "workload": mine["workload"].replace("1 GPU", f"{world} GPU(s), "
                                "independent proofs on every GPU"),
                                "prove_per_s": float(sum(v[0].item() for v in per_gpu)), "verify_per_s": float(sum(v[1].item() for v in per_gpu)),
+                               "prove_in_batches_of_128_per_s": float(sum(v[2].item() for v in per_gpu)),
+                               "per_gpu_prove_in_batches_of_128_per_s": [float(v[2].item()) for v in per_gpu],
                                "per_gpu_prove_per_s": [float(v[0].item()) for v in per_gpu],
                                "per_gpu_verify_per_s": [float(v[1].item()) for v in per_gpu], "host_threads_per_gpu": mine["host_threads"],
                                "one_at_a_time": mine["one_at_a_time"]}
