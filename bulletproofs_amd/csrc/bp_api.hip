@@ -346,7 +346,7 @@ int msm_device(bp_ctx* ctx, int curve, const MsmPart& p0, const MsmPart& p1, Msm
                u32** d_windows, int groups = 1, const MsmExtra* extra = nullptr, const MsmTable* table = nullptr,
                bool win_host = false, size_t host_extra = 0, int batch = 1) {
   size_t n = p0.n + p1.n + (extra ? 2 : 0);
-  hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan, table ? table->stride : 0, true, batch);
+  hipError_t e = msm_make_plan(curve, n, ctx->c_override, groups, plan, table ? table->stride : 0, true, batch, table ? table->bits : 8);
   if (e != hipSuccess) return fail(ctx, BP_E_ARG, "msm plan (n too large?)", e);
   MsmWorkspace ws{};
   void* p;
@@ -2411,6 +2411,7 @@ struct bp_range_batch {
   // then the length of a row of the per-proof arrays (n before, n >> reb_rounds after), and the rounds read
   // the batch's own points (B rows of 2 row + 1: G' | H' | u) and their window tables.
   int reb_rounds = 0;
+  int reb_bits = 4;  // digit width of the tables over the batch's own points
   bool rebased = false;
   size_t row = 0;
   void* reb_block = nullptr;
@@ -2479,7 +2480,8 @@ int rangeb_rebase(bp_range_batch* rb) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     const size_t o_x = take(B * pts * 32), o_y = take(B * pts * 32), o_inf = take(B * pts);
-    const size_t o_tab = take((size_t)kTableWindows * B * pts * 64), o_scr = take((size_t)kTableWindows * B * pts * 128);
+    const size_t tab_windows = 256 / (size_t)rb->reb_bits;
+    const size_t o_tab = take(tab_windows * B * pts * 64), o_scr = take(tab_windows * B * pts * 128);
     const size_t o_cols = take(B * 2 * m * 32), o_prog = take(B * 2 * kRebaseTabProgMax * sizeof(u32));
     hipError_t e = hipMalloc(&rb->reb_block, off);
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? BP_E_OOM : BP_E_HIP, "rangeb_rebase: allocation", e);
@@ -2521,7 +2523,7 @@ int rangeb_rebase(bp_range_batch* rb) {
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "ipab_rebase_pack", e);
   std::swap(rb->a, rb->a2);
   std::swap(rb->b, rb->b2);
-  e = launch_window_tables_inv1(rb->curve, rb->reb_x, rb->reb_y, rb->reb_inf, B * pts, kTableWindowBits, kTableWindows, rb->reb_scratch,
+  e = launch_window_tables_inv1(rb->curve, rb->reb_x, rb->reb_y, rb->reb_inf, B * pts, rb->reb_bits, 256 / rb->reb_bits, rb->reb_scratch,
                                 rb->reb_tab, ctx->stream);
   if (e != hipSuccess) return fail(ctx, BP_E_HIP, "window_tables_inv1", e);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // `prog` goes out of scope
@@ -2565,6 +2567,8 @@ int bp_range_batch_begin(bp_ctx* ctx, const bp_bases* bases, size_t batch, size_
     if (const char* ev = getenv("BP_RANGE_BATCH_REBASE")) rounds = atoi(ev);
     if (rounds < 1 || rounds > 8 || (n >> rounds) < 32 || batch < 4) rounds = 0;
     rb->reb_rounds = rounds;
+    // BP_RANGE_BATCH_TAB_BITS=8 keeps byte digits over the replaced generators (comparison runs)
+    if (const char* ev = getenv("BP_RANGE_BATCH_TAB_BITS")) rb->reb_bits = atoi(ev) == 8 ? 8 : 4;
   }
   // powers of y by two tables of about sqrt(n) entries
   u32 lo = 1;
@@ -2765,7 +2769,7 @@ int bp_range_batch_round_lr(bp_range_batch* rb, uint64_t* out_lr_xyz) {
     // the batch's own points: row b = G'_b (n) | H'_b (n) | u
     gx = rb->reb_x; gy = rb->reb_y; hx = rb->reb_x + n * 8; hy = rb->reb_y + n * 8;
     ginf = rb->reb_inf; hinf = rb->reb_inf + n;
-    table = MsmTable{rb->reb_tab, (size_t)rb->batch * (2 * n + 1), 2 * n + 1};
+    table = MsmTable{rb->reb_tab, (size_t)rb->batch * (2 * n + 1), 2 * n + 1, rb->reb_bits};
   }
   MsmPart pg{gx, gy, ginf, rb->eg, n};
   pg.sel_half = h; pg.group_hi = 0; pg.group_lo = 1;

@@ -185,6 +185,9 @@ struct MsmTable {
   size_t stride = 0;
   // batched plans: problem b's points sit sess_stride base indices after problem 0's (0: one base set for all)
   size_t sess_stride = 0;
+  // digit width of the tables: record (w, j) = 2^(bits w) * P_j, 256 / bits windows.  8 for registered base sets;
+  // 4 for the folded generators of a batch (few points per window: eight buckets instead of 128 to reduce)
+  int bits = 8;
 };
 constexpr int kTableWindowBits = 8;
 constexpr int kTableWindows = 32;
@@ -241,7 +244,7 @@ struct MsmPipe {
 int msm_choose_window(size_t n);
 int msm_default_window(size_t n);
 hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride = 0,
-                         bool allow_stages = false, int batch = 1);
+                         bool allow_stages = false, int batch = 1, int table_bits = 8);
 constexpr int kMsmMaxBatch = 128;
 // out[q] = sum of the `count` XYZZ points (AoS, 32 words, boundary form) in + (q * count) * 32, q < n_sums: the
 // window sums of a table plan whose windows carry their powers of two already (finish_c == 0), added on the

@@ -100,7 +100,7 @@ static int key_bits_for(u32 max_key) {
 }
 
 hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride,
-                         bool allow_stages, int batch) {
+                         bool allow_stages, int batch, int table_bits) {
   MsmPlan p{};
   if (groups < 1 || groups > 2 || batch < 1 || batch > kMsmMaxBatch) return hipErrorInvalidValue;
   p.groups = groups;
@@ -109,17 +109,18 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   p.c = (c_override >= 2 && c_override <= 20) ? c_override : msm_choose_window(n_total / groups);
   const bool small_ok = n_total > 0 && n_total <= kSmallMaxPoints && !getenv("BP_MSM_NO_SMALL");
   if (small_ok && !(c_override >= 2 && c_override <= 20)) p.c = n_total / groups >= 512 ? 8 : 4;
-  if (p.tab) p.c = kTableWindowBits;
+  if (p.tab && table_bits != kTableWindowBits && !(table_bits == 4 && batch > 1)) return hipErrorInvalidValue;
+  if (p.tab) p.c = table_bits;
   // k_digits maps a scalar k > r/2 to r - k (and negates the point), so digits
   // come from a value below 2^255 (secp256k1) or 2^254 (Vesta); one more bit
   // absorbs the carry of the signed recoding.
   const int value_bits = curve == BP_VESTA ? 254 : 255;
   p.group_windows = (value_bits + 1 + p.c - 1) / p.c;
   p.digit_windows = p.group_windows;
-  p.tab_virtual = p.tab && small_ok && p.digit_windows * groups <= 64 && !getenv("BP_MSM_TAB_MERGED");
+  p.tab_virtual = p.tab && small_ok && (p.digit_windows * groups <= 64 || batch > 1) && !getenv("BP_MSM_TAB_MERGED");
   p.finish_c = p.tab_virtual ? 0 : p.c;
   if (p.tab) {
-    if (p.digit_windows > kTableWindows) return hipErrorInvalidValue;
+    if (p.digit_windows > 256 / table_bits) return hipErrorInvalidValue;
     // every digit window lands in the one bucket set of its group: one output "window" per group
     // (unless the plan keeps them apart, see tab_virtual)
     if (!p.tab_virtual) p.group_windows = 1;
@@ -180,7 +181,7 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   p.wshift = 31 - wbits;
   if (batch > 1) p.wshift = 31;  // batched plans keep no window number in the value word (nothing reads it on their path)
   if (n_total >= ((size_t)1 << p.wshift)) return hipErrorInvalidValue;
-  if (p.tab && (size_t)kTableWindows * table_stride >= ((size_t)1 << p.wshift)) return hipErrorInvalidValue;
+  if (p.tab && (size_t)(256 / table_bits) * table_stride >= ((size_t)1 << p.wshift)) return hipErrorInvalidValue;
   p.sort_tmp_bytes = 256;
   // chunk length: up to 24 entries, shorter when the problem is small so that there are still
   // tens of thousands of lanes (2^20 points, 16-bit windows, per step: 1.485 ms at 16, 1.450 at 24,
@@ -611,11 +612,19 @@ __global__ __launch_bounds__(1024) void k_small_front(
 // converts a scalar once for all of them: a counting pass (one histogram per window in LDS), the bucket
 // offsets, then the same walk again to place the entries.  Table plans only (8-bit digits, entries name
 // table records); the outputs are k_small_front's.
-constexpr int kTabFrontWindows = 8;
-static_assert(kTableWindowBits == 8 && kTableWindows % kTabFrontWindows == 0, "digits are the bytes of the scalar");
-constexpr u32 kTabFrontBuckets = 1u << (kTableWindowBits - 1);
+// CB: digit width of the tables, 8 (digits are the bytes of the scalar; 8 windows of 128 buckets per block) or
+// 4 (its nibbles; all 64 windows of 8 buckets in one block).
+template <int CB>
+struct TabFront {
+  static_assert(CB == 8 || CB == 4, "byte or nibble digits");
+  static constexpr int kAllWindows = 256 / CB;
+  static constexpr u32 kBuckets = 1u << (CB - 1);
+  static constexpr int kWindows = CB == 8 ? 8 : 64;  // per block
+  static constexpr u32 kSlots = (u32)kWindows * kBuckets;
+  static_assert(kSlots <= (u32)kSmallThreads && kAllWindows % kWindows == 0, "a bucket per lane at most");
+};
 
-template <class C>
+template <class C, int CB>
 __global__ __launch_bounds__(1024) void k_tab_front(const u32* __restrict__ s0, const uint8_t* __restrict__ inf0, size_t n0,
                                                     const u32* __restrict__ s1, const uint8_t* __restrict__ inf1, size_t n1,
                                                     DigitGroups sel, int group_windows, int wshift,
@@ -623,8 +632,11 @@ __global__ __launch_bounds__(1024) void k_tab_front(const u32* __restrict__ s0, 
                                                     u32* __restrict__ bucket_end, u32* __restrict__ heavy_count, u32 tab_stride,
                                                     u32 tab_off0, u32 tab_off1) {
   using Fr = typename C::Fr;
-  __shared__ u32 hist[kTabFrontWindows * kTabFrontBuckets];
-  __shared__ u32 cursor[kTabFrontWindows * kTabFrontBuckets];
+  using TF = TabFront<CB>;
+  constexpr int kTabFrontWindows = TF::kWindows;
+  constexpr u32 kTabFrontBuckets = TF::kBuckets;
+  __shared__ u32 hist[TF::kSlots];
+  __shared__ u32 cursor[TF::kSlots];
   __shared__ u32 wave_sums[kSmallThreads / 64 + 1];
   const u32 sess = blockIdx.y;
   s0 += (size_t)sess * sel.s_stride0;
@@ -694,14 +706,14 @@ __global__ __launch_bounds__(1024) void k_tab_front(const u32* __restrict__ s0, 
       }
       const u32 j = sess * sel.tab_sess_stride +
                     (is_extra ? sel.extra_tab[i - n01] : second ? tab_off1 + (u32)(i - n0) : tab_off0 + (u32)i);
-      // signed digits in (-128, 128] from the bytes, low to high, with the carry of the windows below
+      // signed digits in (-2^(CB-1), 2^(CB-1)] from the bytes or nibbles, low to high, with the carry of the windows below
       u32 carry = 0;
 #pragma unroll
-      for (int w = 0; w < kTableWindows; w++) {
-        const u32 v = ((k.v[w >> 2] >> (8 * (w & 3))) & 255u) + carry;
+      for (int w = 0; w < TF::kAllWindows; w++) {
+        const u32 v = CB == 8 ? ((k.v[w >> 2] >> (8 * (w & 3))) & 255u) + carry : ((k.v[w >> 3] >> (4 * (w & 7))) & 15u) + carry;
         carry = v > kTabFrontBuckets ? 1u : 0u;
         if ((u32)w < w_first || (u32)w >= w_first + kTabFrontWindows || (int)w >= group_windows) continue;
-        const u32 mag = carry ? 256u - v : v;
+        const u32 mag = carry ? (1u << CB) - v : v;
         if (mag == 0) continue;
         const u32 slot = ((u32)w - w_first) * kTabFrontBuckets + mag - 1;
         if constexpr (!PLACE) {
@@ -716,21 +728,21 @@ __global__ __launch_bounds__(1024) void k_tab_front(const u32* __restrict__ s0, 
   };
   walk(std::false_type{});
   __syncthreads();
-  // bucket offsets: lane t owns bucket t of the block's kTabFrontWindows x 128 (one each at 1024 lanes)
-  static_assert(kTabFrontWindows * kTabFrontBuckets == kSmallThreads, "one bucket per lane");
+  // bucket offsets: lane t owns bucket t of the block (windows x buckets per window, at most one per lane)
   {
-    const u32 b = threadIdx.x, wl = b / kTabFrontBuckets;
-    const u32 mine = hist[b];
+    const bool owner = threadIdx.x < TF::kSlots;  // lanes beyond the block's buckets only take part in the scan
+    const u32 b = owner ? threadIdx.x : 0u, wl = b / kTabFrontBuckets;
+    const u32 mine = owner ? hist[b] : 0u;
     u32 total;
     const u32 before = block_exclusive_scan(mine, wave_sums, &total);  // over all of the block's windows
     // the entries of window wl start at its slice; those of the windows before it in this block are not in it
     __shared__ u32 win_base[kTabFrontWindows];
-    if ((b % kTabFrontBuckets) == 0) win_base[wl] = before;
+    if (owner && (b % kTabFrontBuckets) == 0) win_base[wl] = before;
     __syncthreads();
     const u32 gwid = gw_first + wl;
     const u32 st = gwid * (u32)n + (before - win_base[wl]);
-    cursor[b] = st;
-    if ((int)(w_first + wl) < group_windows) {
+    if (owner) cursor[b] = st;
+    if (owner && (int)(w_first + wl) < group_windows) {
       bucket_start[(size_t)gwid * kTabFrontBuckets + (b % kTabFrontBuckets)] = st;
       bucket_end[(size_t)gwid * kTabFrontBuckets + (b % kTabFrontBuckets)] = st + mine;
     }
@@ -2524,14 +2536,23 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     sel.s_stride0 = (u32)p0.batch_stride;
     sel.s_stride1 = (u32)p1.batch_stride;
     static const bool no_tab_front = getenv("BP_MSM_NO_TAB_FRONT") != nullptr;
-    if (plan.batch > 1 && plan.tab_virtual && plan.group_windows % kTabFrontWindows == 0 && !no_tab_front) {
+    const int front_windows = plan.c == 8 ? TabFront<8>::kWindows : TabFront<4>::kWindows;
+    if (plan.batch > 1 && plan.tab_virtual && (plan.c == 8 || plan.c == 4) && plan.group_windows % front_windows == 0 && !no_tab_front) {
       // a batch has blocks enough for each to take several digit windows and convert a scalar once for them
-      const unsigned parts = (unsigned)(plan.group_windows / kTabFrontWindows);
+      const unsigned parts = (unsigned)(plan.group_windows / front_windows);
       sel.tab_sess_stride = (u32)table->sess_stride;
-      DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_tab_front<C>, dim3(parts * (unsigned)plan.groups, (unsigned)plan.batch),
-                                               dim3(kSmallThreads), 0, st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, sel,
-                                               plan.group_windows, plan.wshift, ws.vals_b, ws.bucket_start, ws.bucket_end,
-                                               ws.heavy_count, (u32)table->stride, (u32)p0.tab_offset, (u32)p1.tab_offset));
+      DISPATCH_CURVE(curve, {
+        if (plan.c == 8)
+          hipLaunchKernelGGL((k_tab_front<C, 8>), dim3(parts * (unsigned)plan.groups, (unsigned)plan.batch), dim3(kSmallThreads), 0,
+                             st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, sel, plan.group_windows, plan.wshift, ws.vals_b,
+                             ws.bucket_start, ws.bucket_end, ws.heavy_count, (u32)table->stride, (u32)p0.tab_offset,
+                             (u32)p1.tab_offset);
+        else
+          hipLaunchKernelGGL((k_tab_front<C, 4>), dim3(parts * (unsigned)plan.groups, (unsigned)plan.batch), dim3(kSmallThreads), 0,
+                             st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, sel, plan.group_windows, plan.wshift, ws.vals_b,
+                             ws.bucket_start, ws.bucket_end, ws.heavy_count, (u32)table->stride, (u32)p0.tab_offset,
+                             (u32)p1.tab_offset);
+      });
       if ((e = hipGetLastError()) != hipSuccess) return e;
       return msm_run_tail(curve, plan, ws, st, ev_acc0, ev_acc1, table->rec);
     }
@@ -2723,7 +2744,8 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
     // 0.209 -> 0.170 ms, no change at 2^17 where the next rule asks for as many anyway; four waves per
     // SIMD lose again, 0.25 ms), and at least one per 32 expected entries
     int lanes = 64;
-    size_t lane_cap = plan.mid ? 131072 : 65536;
+    // batched plans are sized for throughput: up to four waves per SIMD
+    size_t lane_cap = plan.mid ? 131072 : plan.batch > 1 ? 262144 : 65536;
     if (const char* ev = getenv("BP_MSM_TREE_LANES")) lane_cap = (size_t)atol(ev);  // tuning runs
     while (lanes > 1 && nbt * (size_t)lanes > lane_cap) lanes >>= 1;
     const size_t per_bucket = plan.entries * (size_t)plan.batch / (nbt ? nbt : 1);
@@ -2735,9 +2757,15 @@ static hipError_t msm_accumulate(int curve, const MsmPlan& plan, const MsmWorksp
     // would set the length of the launch's chain: it goes to a block of its own.  A scalar
     // field well below 2^256 fills its top window this unevenly on every input.
     size_t per_lane = 2 * ((per_bucket + (size_t)lanes - 1) / (size_t)lanes);
-    if (per_lane < 16) per_lane = 16;
+    static const char* heavy_env = getenv("BP_MSM_TREE_HEAVY_MIN");  // tuning runs
+    const size_t heavy_min = heavy_env ? (size_t)atol(heavy_env) : 16;
+    if (per_lane < heavy_min) per_lane = heavy_min;
     const u32 heavy_from = (u32)(per_lane * (size_t)lanes);
     const size_t tree_threads = nbt * (size_t)lanes;
+    static const bool plan_trace = getenv("BP_MSM_PLAN_TRACE") != nullptr;  // tuning runs: one line per launch
+    if (plan_trace)
+      fprintf(stderr, "msm_accumulate: n_total %zu batch %d c %d windows %d buckets %u entries %zu per_bucket %zu lanes %d heavy_from %u\n",
+              plan.n_total, plan.batch, plan.c, plan.n_windows, plan.n_buckets, plan.entries, per_bucket, lanes, heavy_from);
     // A bucket holds at most the entries of its window, n_total.  When that is within an eighth
     // of kTreeHeavyMax (the IPA rounds of a 4096-bit range proof: 8194) the blocks inside the
     // launch take every crowded bucket, nothing can be queued, and the launch for the queue is
@@ -2832,10 +2860,11 @@ static hipError_t msm_reduce(int curve, const MsmPlan& plan, const MsmWorkspace&
   // window would leave most of it waiting for 4096 chains made as short as one can be
   static const int lanes_from = getenv("BP_MSM_REDUCE_LANES_FROM") ? atoi(getenv("BP_MSM_REDUCE_LANES_FROM")) : 512;
   static const int lanes_log = getenv("BP_MSM_REDUCE_LPW_LOG") ? atoi(getenv("BP_MSM_REDUCE_LPW_LOG")) : 4;
-  if (plan.n_windows >= lanes_from && plan.n_buckets >= 2 * kReduceLanesMax && plan.n_buckets <= 256) {
+  if (plan.n_windows >= lanes_from && plan.n_buckets >= 8 && plan.n_buckets <= 256) {
     int log_nb = 0;
     while ((1u << log_nb) < plan.n_buckets) log_nb++;
-    const int log_lpw = lanes_log >= 1 && lanes_log <= 6 ? lanes_log : 4;
+    int log_lpw = lanes_log >= 1 && lanes_log <= 6 ? lanes_log : 4;
+    if (log_lpw > log_nb) log_lpw = log_nb;  // a lane per bucket at most (8 buckets per window: 8 lanes)
     const size_t threads = (size_t)plan.n_windows << log_lpw;
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_window_reduce_lanes<C>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
                                              ws.buckets, nbt, plan.n_buckets, log_lpw, log_nb - log_lpw, (u32)plan.n_windows,
