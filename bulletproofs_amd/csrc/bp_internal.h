@@ -227,6 +227,10 @@ struct MsmPlan {
   // problems (problem b owns windows [b * n_windows / batch, (b + 1) * n_windows / batch)), n_total and
   // entries those of one problem
   int batch;
+  // > 0 (two-level plans whose width does not divide 256): every scalar k is taken as k + t r with a per-point
+  // t < spread_t (a power of two; r P = 0, the sum is the same), so that the values fill group_windows * c - 1
+  // bits evenly and the top window is as full as the others; no folding to |k| <= r/2 then
+  u32 spread_t;
 };
 
 // Large single-sum plans run their windows in batches: sorting and the chunk table of batch

@@ -99,8 +99,8 @@ static int key_bits_for(u32 max_key) {
   return b;
 }
 
-hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride,
-                         bool allow_stages, int batch, int table_bits) {
+static hipError_t make_plan_impl(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride,
+                                 bool allow_stages, int batch, int table_bits, bool allow_spread) {
   MsmPlan p{};
   if (groups < 1 || groups > 2 || batch < 1 || batch > kMsmMaxBatch) return hipErrorInvalidValue;
   p.groups = groups;
@@ -116,6 +116,20 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   // absorbs the carry of the signed recoding.
   const int value_bits = curve == BP_VESTA ? 254 : 255;
   p.group_windows = (value_bits + 1 + p.c - 1) / p.c;
+  // A width that does not divide 256 leaves a short top window: all points in a few buckets, which then need a
+  // deep tree of partial sums.  Where the front end can (the two-level counting sort, checked below) the scalars
+  // are spread instead: k + t r with t < 2^s fills W c - 1 bits evenly (the modulus is below 2^mod_bits), W the
+  // fewest windows that leave s >= 1.
+  const int mod_bits = curve == BP_VESTA ? 255 : 256;
+  int spread_windows = 0;
+  if (!p.tab && batch == 1 && !small_ok && 256 % p.c != 0 && p.c >= kTwoLevelLoBits + 2 && p.c <= 16 &&
+      allow_spread) {
+    spread_windows = (mod_bits + 2 + p.c - 1) / p.c;
+    int s_bits = spread_windows * p.c - 1 - mod_bits;
+    if (s_bits > 16) s_bits = 16;
+    p.spread_t = 1u << s_bits;
+    p.group_windows = spread_windows;
+  }
   p.digit_windows = p.group_windows;
   p.tab_virtual = p.tab && small_ok && (p.digit_windows * groups <= 64 || batch > 1) && !getenv("BP_MSM_TAB_MERGED");
   p.finish_c = p.tab_virtual ? 0 : p.c;
@@ -236,6 +250,8 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
                 (size_t)groups * (p.n_buckets >> kTwoLevelLoBits) <= (1u << kTwoLevelLoBits) &&
                 (size_t)p.n_windows * (p.n_buckets >> kTwoLevelLoBits) <= kTwoLevelMaxBins &&
                 nbt + 2 >= 2 * (size_t)kTwoLevelMaxBins && !getenv("BP_MSM_RADIX");
+  // no spreading on the other front ends: the caller plans again with folded scalars
+  if (p.spread_t && !p.two_level) return hipErrorNotSupported;
   if (!p.small && !p.mid && !p.two_level) {
     // only the plans that still sort with the library's radix sort (more than 2^22 points, window
     // widths without a high bucket part, BP_MSM_RADIX) ask it for its temporary storage
@@ -256,6 +272,15 @@ hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, 
   p.csort_tmp_bytes = 256;
   *plan = p;
   return hipSuccess;
+}
+
+hipError_t msm_make_plan(int curve, size_t n_total, int c_override, int groups, MsmPlan* plan, size_t table_stride,
+                         bool allow_stages, int batch, int table_bits) {
+  static const bool no_spread = getenv("BP_MSM_NO_SPREAD") != nullptr;  // comparison runs
+  hipError_t e = make_plan_impl(curve, n_total, c_override, groups, plan, table_stride, allow_stages, batch, table_bits, !no_spread);
+  if (e == hipErrorNotSupported)
+    e = make_plan_impl(curve, n_total, c_override, groups, plan, table_stride, allow_stages, batch, table_bits, false);
+  return e;
 }
 
 // ---- 1. digits --------------------------------------------------------------
@@ -1091,7 +1116,7 @@ __global__ __launch_bounds__(1024) void k_two_digits(const u32* __restrict__ s0,
                                                      DigitGroups sel, int c, int group_windows, int groups,
                                                      u32 n_hi, u32* __restrict__ packed,
                                                      uint16_t* __restrict__ digits, uint8_t* __restrict__ flips,
-                                                     u32* __restrict__ part_count) {
+                                                     u32* __restrict__ part_count, u32 spread_t) {
   using Fr = typename C::Fr;
   __shared__ u32 hist[kTwoMaxBins];
   const size_t n01 = n0 + n1, n = n01 + sel.n_extra;
@@ -1107,6 +1132,7 @@ __global__ __launch_bounds__(1024) void k_two_digits(const u32* __restrict__ s0,
     const bool second = ii >= n0, is_extra = ii >= n01;
     const u32 wbase = (groups > 1 ? digit_group_of(sel, ii, n0, n01) : 0u) * (u32)group_windows;
     Fe k = fe_zero();
+    u32 k8 = 0;  // ninth limb of a spread scalar
     bool is_inf = true;
     u32 flip = 0;
     if (live) {
@@ -1122,19 +1148,32 @@ __global__ __launch_bounds__(1024) void k_two_digits(const u32* __restrict__ s0,
       fe_store(packed + ii * 16 + 8, fe_import<C>(fe_load(py)));
       is_inf = is_extra ? false : (second ? (inf1 && inf1[ii - n0]) : (inf0 && inf0[ii]));
       k = fe_from_mont<Fr>(fe_load(sp));
-      // |k| <= r/2: use r - k with the point negated when that is the smaller value
-      Fe nk = fe_neg<Fr>(k);
-      bool gt = false, decided = false;
+      if (spread_t) {
+        // k + t r, t < spread_t by the point's number (see MsmPlan::spread_t): nine limbs, no folding
+        const u32 t = (u32)(((u32)ii * 2654435761u) >> 12) & (spread_t - 1u);
+        unsigned long long acc = 0;
 #pragma unroll
-      for (int t = 7; t >= 0; t--) {
-        if (!decided && k.v[t] != nk.v[t]) {
-          gt = k.v[t] > nk.v[t];
-          decided = true;
+        for (int q = 0; q < 8; q++) {
+          acc += (unsigned long long)t * Fr::mod(q) + k.v[q];
+          k.v[q] = (u32)acc;
+          acc >>= 32;
         }
-      }
-      if (gt) {
-        k = nk;
-        flip = 1;
+        k8 = (u32)acc;
+      } else {
+        // |k| <= r/2: use r - k with the point negated when that is the smaller value
+        Fe nk = fe_neg<Fr>(k);
+        bool gt = false, decided = false;
+#pragma unroll
+        for (int t = 7; t >= 0; t--) {
+          if (!decided && k.v[t] != nk.v[t]) {
+            gt = k.v[t] > nk.v[t];
+            decided = true;
+          }
+        }
+        if (gt) {
+          k = nk;
+          flip = 1;
+        }
       }
       flips[ii] = (uint8_t)flip;
     }
@@ -1142,13 +1181,15 @@ __global__ __launch_bounds__(1024) void k_two_digits(const u32* __restrict__ s0,
     for (int w = 0; w < n_windows; w++) {
       const int bit = w * c, limb = bit >> 5, sh = bit & 31;
       u32 raw = 0;
-      if (limb < 8) {
+      if (limb < 9) {
         u32 lo = 0, hi = 0;
 #pragma unroll
         for (int t = 0; t < 8; t++) {
           lo = (t == limb) ? k.v[t] : lo;
           hi = (t == limb + 1) ? k.v[t] : hi;
         }
+        lo = limb == 8 ? k8 : lo;
+        hi = limb == 7 ? k8 : hi;
         unsigned long long two = ((unsigned long long)hi << 32) | lo;
         raw = (u32)(two >> sh) & mask;
       }
@@ -2373,7 +2414,6 @@ hipError_t launch_window_combine(int curve, const u32* windows, int n_parts, int
 // Every lane keeps its two points in LDS and ONE inlined addition serves every step (operands are chosen by
 // address; a doubling is the addition of a point to itself): with an addition per step the body was 100 KB
 // of code against a 64 KiB instruction cache, and a lane waited for instructions more than for results.
-constexpr u32 kReduceLanesMax = 64;
 
 // point `which` (0 run, 1 acc) of lane `lane` of a block of 256: word k at (which * 32 + k) * 256 + lane, so
 // the lanes of a wave touch different banks
@@ -2624,7 +2664,7 @@ hipError_t msm_run(int curve, const MsmPart& p0, const MsmPart& p1, const MsmExt
     DISPATCH_CURVE(curve, hipLaunchKernelGGL(k_two_digits<C>, dim3((unsigned)((n + kTwoDigitPoints - 1) / kTwoDigitPoints)),
                                              dim3(1024), 0, st, p0.s, p0.inf, p0.n, p1.s, p1.inf, p1.n, p0.x, p0.y, p1.x,
                                              p1.y, sel, plan.c, plan.group_windows, plan.groups, n_hi, ws.packed, digits,
-                                             flips, part_count));
+                                             flips, part_count, plan.spread_t));
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(k_two_scatter, dim3((unsigned)((n + kTwoScatterPoints - 1) / kTwoScatterPoints), gw), dim3(1024), 0,
                        st, digits, flips, part_count, sel, p0.n, p1.n, size0, gw, (u32)plan.groups, n_hi, cursor,

@@ -423,6 +423,28 @@ def test_msm_path_boundaries(ctx, coracle, c, n):
         ctx.set_msm_window(0)
 
 
+@pytest.mark.parametrize("c", CURVES, ids=ids)
+@pytest.mark.parametrize("n", [40000, 70001])
+def test_msm_spread_scalars(ctx, coracle, c, n):
+    """Window widths that do not divide 256 on the two-level counting sort: every scalar is taken as
+    k + t r (r P is the identity), so that the top window fills like the others.  Same group element as
+    the oracle's, with identity bases and 0, +-1, +-2 among the scalars, and with the spreading off."""
+    px, py = seeded_points(coracle, c, n, 17 + n, 1201)
+    ints, K = random_scalars(c, n, n + 1)
+    special = o.pack_field([0, 1, c.n - 1, 2, c.n - 2], c.n)
+    K[200:205] = special
+    K[n - 5:] = special
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[[3, 20000, n - 2]] = 1
+    exp = coracle.msm(c.id, (px, py, inf), K, 8)
+    try:
+        for w in (10, 11, 12, 13, 14, 15):
+            ctx.set_msm_window(w)
+            assert np.array_equal(ctx.msm_unchecked(c.id, (px, py, inf), K), exp), w
+    finally:
+        ctx.set_msm_window(0)
+
+
 def test_msm_beyond_baseline_size(ctx, coracle):
     """2^23 points (8 copies of 2^20): sum_j <K_j, P> == <sum_j K_j, P>.  At this size the
     accumulation chunks are longer than at 2^20, whose result the closed form pins."""
