@@ -49,7 +49,7 @@ PEAK_PROBE_ITERS = 12000  # one probe launch runs >= 50 ms
 # launches; profiles/r02_v5_pmc_summary.csv).  The counters read KiB; a
 # scattered read of 64-byte records with a known byte count (tools/calib_gather.py,
 # profiles/r01_gather64_calibration.csv) reads back exactly, so no factor is applied.
-PMC_TRAFFIC_2_20 = {"fetch_bytes": 1220025.9 * 1024, "write_bytes": 125880.7 * 1024}
+PMC_TRAFFIC_2_20 = {"fetch_bytes": 1222888.0 * 1024, "write_bytes": 125880.1 * 1024}
 CPU_MSM_SAMPLES = 5
 
 
@@ -773,7 +773,7 @@ def main():
                         "(all launches and the host's part, ms_per_step) at the bucket method's count per point",
                 "traffic": (PMC_TRAFFIC_2_20["fetch_bytes"] + PMC_TRAFFIC_2_20["write_bytes"]) if args.log2n == LOG2_N and args.scaling == "weak" else None,
                 "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc runs of this command, taken from "
-                                "profiles/r02_v5_pmc_summary.csv: a constant from profiles/, not counted in this run)",
+                                "profiles/r03_v5_pmc_summary.csv, the 2^20-point launches: a constant from profiles/, not counted in this run)",
                 "algorithmic_bytes": float(n) * nw * (64 + 4),
             },
         }
