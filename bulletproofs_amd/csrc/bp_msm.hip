@@ -2544,25 +2544,48 @@ __global__ __launch_bounds__(256) void k_window_reduce_lanes(const u32* __restri
   if (live && j == 0) xyzz_store_aos(windows + (size_t)w * 32, xyzz_export<C>(reduce_lds_load(pts, ACC, tid)));
 }
 
-// one wave per sum: lane l < count holds point l, a shuffle tree joins them (count <= 64)
+// One block of 32 quads per sum: the count <= 64 points sit in LDS and a tree joins them, every addition spread
+// over four lanes (bp_quad.h).  The tree is a chain of six dependent additions on lanes that have the CU to
+// themselves, so what counts is the time of one addition: a wave with a lane per point and a shuffle tree
+// took 60 us where this takes about 20.
+constexpr int kGroupSumThreads = 128;
+
 template <class C>
-__global__ __launch_bounds__(64) void k_window_group_sums(const u32* __restrict__ in, int count, u32* __restrict__ out) {
+__global__ __launch_bounds__(kGroupSumThreads) void k_window_group_sums(const u32* __restrict__ in, int count,
+                                                                        u32* __restrict__ out) {
   using F = typename C::Fq;
-  const int lane = threadIdx.x;
-  Xyzz acc = lane < count ? xyzz_load_aos(in + ((size_t)blockIdx.x * count + lane) * 32) : xyzz_identity<F>();
-  for (int off = 32; off > 0; off >>= 1) {
-    Xyzz o = xyzz_shfl_down(acc, off, 64);
-    if (lane < off) xyzz_add<F>(acc, o);
+  __shared__ u32 pts[64 * 32];
+  __shared__ u32 scr_all[(kGroupSumThreads / 4) * kQuadScratch * 8];
+  __shared__ u32 zero[8];
+  const u32 tid = threadIdx.x, quad = tid >> 2;
+  const int role = (int)(tid & 3u), coord = quad_coord(role);
+  u32* scr = scr_all + quad * (kQuadScratch * 8);
+  if (tid < 8) zero[tid] = 0;
+  const Fe one = fe_one<F>();
+  for (u32 i = tid; i < 64 * 4; i += kGroupSumThreads) {
+    const u32 slot = i >> 2, c = i & 3;
+    const Fe v = (int)slot < count ? fe_load(in + ((size_t)blockIdx.x * count + slot) * 32 + c * 8) : quad_identity_coord((int)c, one);
+    fe_store(pts + slot * 32 + c * 8, v);
   }
-  if (lane == 0) xyzz_store_aos(out + (size_t)blockIdx.x * 32, acc);
+  __syncthreads();
+  for (u32 half = 32; half > 0; half >>= 1) {
+    if (quad < half) {
+      Fe v;
+      const bool changed = quad_add<F>(pts, scr, zero, quad, quad + half, role, v);
+      quad_sync();
+      if (changed) fe_store(pts + quad * 32 + coord * 8, v);
+    }
+    __syncthreads();
+  }
+  if (quad == 0) fe_store(out + (size_t)blockIdx.x * 32 + coord * 8, fe_load(pts + coord * 8));
 }
 
 hipError_t launch_window_group_sums(int curve, const u32* in, int count, int n_sums, u32* out, hipStream_t st) {
   if (count < 1 || count > 64 || n_sums < 1) return hipErrorInvalidValue;
   if (curve == BP_SECP256K1)
-    hipLaunchKernelGGL(k_window_group_sums<Secp256k1>, dim3((unsigned)n_sums), dim3(64), 0, st, in, count, out);
+    hipLaunchKernelGGL(k_window_group_sums<Secp256k1>, dim3((unsigned)n_sums), dim3(kGroupSumThreads), 0, st, in, count, out);
   else if (curve == BP_VESTA)
-    hipLaunchKernelGGL(k_window_group_sums<Vesta>, dim3((unsigned)n_sums), dim3(64), 0, st, in, count, out);
+    hipLaunchKernelGGL(k_window_group_sums<Vesta>, dim3((unsigned)n_sums), dim3(kGroupSumThreads), 0, st, in, count, out);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
